@@ -1,0 +1,265 @@
+"""gpu-fluid-simulation_amd — MI355X-native SPH fluid-step engine (hot path of
+rookieCookies/gpu-fluid-simulation) behind the C ABI in include/fluidsim.h.
+
+This module is the thin Python host mirror used by tests and bench.py; it only
+marshals arguments into libfluidsim_hip.so (hand-written HIP kernels).  There is
+no CPU fallback: without the built extension (or without a GPU) calls raise.
+
+Mirrors, by name and argument meaning:
+  FluidSimulation.new / .tick / .tick_count   src/simulation.rs:139,459,12
+  SimulationSettings / TickSettings           src/simulation.rs:95-122
+  ResizableBuffer                             src/buffer.rs:17-88
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import (  # noqa: F401
+    FS_SORT_BITONIC,
+    FS_SORT_COUNTING,
+    PARTICLE_DTYPE,
+    PASS_NAMES,
+    ExtensionMissing,
+    Options,
+    Settings,
+    SortStep,
+    TickSettings,
+    Uniform,
+    UVec2,
+    Vec2,
+    load_library,
+)
+
+__all__ = [
+    "FluidSimulation", "ResizableBuffer", "SimulationSettings", "default_tick_settings", "dam_break_2d",
+    "FluidSimError", "load_library", "PARTICLE_DTYPE",
+]
+
+
+class FluidSimError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"fluidsim status {status}: {message}")
+        self.status = status
+
+
+def _check(lib, status):
+    if status != _abi.FS_OK:
+        raise FluidSimError(status, lib.fs_last_error().decode("utf-8", "replace"))
+
+
+def SimulationSettings(particle_count=100_000, particle_spacing=0.1, smoothing_radius=0.2, size=(53.0, 53.0),
+                       texture_size=(1024, 1024)):
+    """Defaults: src/main.rs:48-54, src/renderer.rs:16."""
+    return Settings(int(particle_count), float(particle_spacing), float(smoothing_radius),
+                    Vec2(float(size[0]), float(size[1])), UVec2(int(texture_size[0]), int(texture_size[1])))
+
+
+def default_tick_settings(**over):
+    """Defaults: src/renderer.rs:374-388."""
+    t = TickSettings(
+        delta=np.float32(1.0) / np.float32(120.0), gravity=Vec2(0.0, 0.0), mass=1.0, pressure_constant=50.0,
+        rest_density=0.0, damping_factor=0.1, viscosity_coefficient=25.0, surface_tension_treshold=0.1,
+        surface_tension_coefficient=35.0, mouse_force_radius=5.0, mouse_force_power=150.0,
+        mouse_pos=Vec2(0.0, 0.0), mouse_state=0)
+    for k, v in over.items():
+        if k in ("gravity", "mouse_pos"):
+            v = Vec2(float(v[0]), float(v[1]))
+        setattr(t, k, v)
+    return t
+
+
+def dam_break_2d(n):
+    """The benchmark scene of SURVEY.md §8d: reference lattice + defaults, gravity on.
+
+    Returns (settings, initial_offset, tick_settings).  All scene arithmetic in f32.
+    """
+    f = np.float32
+    s, h = f(0.1), f(0.2)
+    L = np.sqrt(f(n)) * s          # block side; exact for the square counts of the benchmark configs
+    size = (f(2.0) * L, f(1.25) * L)
+    off = (-size[0] / f(2) + L / f(2) + s / f(2), size[1] / f(2) - L / f(2) - s / f(2))
+    settings = SimulationSettings(n, s, h, size, (1024, 1024))
+    tick = default_tick_settings(gravity=(0.0, 9.81))
+    return settings, (float(off[0]), float(off[1])), tick
+
+
+class FluidSimulation:
+    """FluidSimulation (src/simulation.rs:10-37) on one MI355X, driven through the C ABI."""
+
+    def __init__(self, settings, device=0, sort_mode=FS_SORT_BITONIC, ref_quirks=True, initial_offset=(0.0, 0.0),
+                 capacity=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.settings = settings
+        opts = Options()
+        self._lib.fs_options_default(C.byref(opts))
+        opts.device = int(device)
+        opts.sort_mode = int(sort_mode)
+        opts.ref_quirks = 1 if ref_quirks else 0
+        opts.initial_offset = Vec2(float(initial_offset[0]), float(initial_offset[1]))
+        opts.capacity = int(capacity)
+        _check(self._lib, self._lib.fs_create_ex(C.byref(settings), C.byref(opts), C.byref(self._h)))
+
+    @classmethod
+    def new(cls, settings, device=0, **kw):
+        return cls(settings, device=device, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.fs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- stepping -----------------------------------------------------------
+    def tick(self, tick_settings):
+        _check(self._lib, self._lib.fs_step(self._h, C.byref(tick_settings)))
+
+    def sync(self):
+        _check(self._lib, self._lib.fs_sync(self._h))
+
+    @property
+    def tick_count(self):
+        return int(self._lib.fs_tick_count(self._h))
+
+    @property
+    def particle_count(self):
+        return int(self._lib.fs_particle_count(self._h))
+
+    @property
+    def grid_dims(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        _check(self._lib, self._lib.fs_grid_dims(self._h, C.byref(w), C.byref(h)))
+        return int(w.value), int(h.value)
+
+    def timed_steps(self, tick_settings, steps):
+        ms = C.c_double()
+        _check(self._lib, self._lib.fs_timed_steps(self._h, C.byref(tick_settings), int(steps), C.byref(ms)))
+        return float(ms.value)
+
+    def profile(self, enable=True):
+        _check(self._lib, self._lib.fs_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * len(PASS_NAMES))()
+        steps = C.c_uint64()
+        _check(self._lib, self._lib.fs_profile_read(self._h, ms, C.byref(steps), 1 if reset else 0))
+        return dict(zip(PASS_NAMES, [float(x) for x in ms])), int(steps.value)
+
+    # -- data ---------------------------------------------------------------
+    def uniform(self):
+        u = Uniform()
+        _check(self._lib, self._lib.fs_get_uniform(self._h, C.byref(u)))
+        return u
+
+    def download_particles(self):
+        out = np.empty(self.particle_count, dtype=PARTICLE_DTYPE)
+        _check(self._lib, self._lib.fs_download_particles(self._h, out.ctypes.data_as(C.c_void_p), out.shape[0]))
+        return out
+
+    def upload_particles(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=PARTICLE_DTYPE)
+        _check(self._lib, self._lib.fs_upload_particles(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0]))
+
+    def download_start_indices(self):
+        w, h = self.grid_dims
+        out = np.empty(w * h, dtype=np.uint32)
+        _check(self._lib, self._lib.fs_download_start_indices(self._h, out.ctypes.data_as(C.c_void_p), out.shape[0]))
+        return out
+
+    def upload_start_indices(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint32)
+        _check(self._lib, self._lib.fs_upload_start_indices(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0]))
+
+    def upload_force_field(self, field):
+        field = np.ascontiguousarray(field, dtype=np.float32)
+        h, w = field.shape[0], field.shape[1]
+        _check(self._lib, self._lib.fs_upload_force_field(self._h, field.ctypes.data_as(C.c_void_p), w, h))
+
+    def particles_device_ptr(self):
+        p = C.c_void_p()
+        _check(self._lib, self._lib.fs_particles_device(self._h, C.byref(p)))
+        return p.value
+
+    def start_indices_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self._lib, self._lib.fs_start_indices_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, int(n.value)
+
+
+class ResizableBuffer:
+    """ResizableBuffer<T> (src/buffer.rs:17-88) over HIP device memory."""
+
+    def __init__(self, name, dtype, length, device=0):
+        self._lib = load_library()
+        self.dtype = np.dtype(dtype)
+        self._h = C.c_void_p()
+        st = self._lib.fs_buffer_create(int(device), self.dtype.itemsize, int(length), name.encode(), C.byref(self._h))
+        _check(self._lib, st)
+
+    def __len__(self):
+        return int(self._lib.fs_buffer_len(self._h))
+
+    def resize(self, new_cap):
+        r = C.c_int()
+        _check(self._lib, self._lib.fs_buffer_resize(self._h, int(new_cap), C.byref(r)))
+        return bool(r.value)
+
+    def write(self, offset, data):
+        data = np.ascontiguousarray(data, dtype=self.dtype)
+        _check(self._lib, self._lib.fs_buffer_write(self._h, int(offset), data.ctypes.data_as(C.c_void_p), data.shape[0]))
+
+    def read(self, offset=0, count=None):
+        count = len(self) - offset if count is None else count
+        out = np.zeros(max(count, 0), dtype=self.dtype)
+        _check(self._lib, self._lib.fs_buffer_read(self._h, int(offset), out.ctypes.data_as(C.c_void_p), out.shape[0]))
+        return out
+
+    @property
+    def device_ptr(self):
+        return self._lib.fs_buffer_device_ptr(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.fs_buffer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def reference_lattice(settings, offset=(0.0, 0.0)):
+    lib = load_library()
+    out = np.zeros(settings.particle_count, dtype=PARTICLE_DTYPE)
+    _check(lib, lib.fs_reference_lattice(C.byref(settings), Vec2(float(offset[0]), float(offset[1])),
+                                         out.ctypes.data_as(C.c_void_p), out.shape[0]))
+    return out
+
+
+def sort_schedule(particle_count):
+    lib = load_library()
+    n = lib.fs_sort_schedule(int(particle_count), None, 0)
+    arr = (SortStep * max(n, 1))()
+    lib.fs_sort_schedule(int(particle_count), arr, n)
+    return [(a.group_width, a.group_height, a.step_index, a.num_values) for a in arr[:n]]
+
+
+def build_uniform(settings, tick_settings, tick_count):
+    lib = load_library()
+    u = Uniform()
+    _check(lib, lib.fs_build_uniform(C.byref(settings), C.byref(tick_settings), int(tick_count), C.byref(u)))
+    return u

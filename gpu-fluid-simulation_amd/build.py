@@ -1,0 +1,62 @@
+"""Build recipe: hipcc --offload-arch=gfx950 -> gpu-fluid-simulation_amd/libfluidsim_hip.so (in-tree).
+
+-ffp-contract=off keeps the kernels' f32 arithmetic in the written association
+(no FMA contraction) so results match the CPU oracle bit for bit.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libfluidsim_hip.so")
+SOURCES = ["engine.hip", "buffer.hip", "kernels_step.hip", "kernels_sort.hip"]
+HEADERS = ["fs_device.h", "fs_kernels.h", os.path.join("..", "..", "include", "fluidsim.h")]
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-ffp-contract=off",
+    "-fno-fast-math",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [sp] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    if force or procs or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,518 @@
+// engine.hip — host side of the C ABI (include/fluidsim.h): simulation handle,
+// SoA device state, pass chain on one HIP stream, AoS import/export.
+//
+// Mirrors FluidSimulation::{new,tick,accessors} (src/simulation.rs:139-564).
+// There is no CPU fallback: every entry point that computes requires a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fluidsim.h"
+#include "fs_kernels.h"
+
+static_assert(sizeof(fs_particle) == 32, "ParticleInstance is 32 bytes (src/simulation.rs:126-135)");
+static_assert(offsetof(fs_particle, predicted_position) == 8 && offsetof(fs_particle, velocity) == 16 &&
+                  offsetof(fs_particle, density) == 24 && offsetof(fs_particle, grid) == 28,
+              "ParticleInstance offsets");
+static_assert(sizeof(fs_uniform) == 120, "SimulationUniform is 120 bytes (src/simulation.rs:53-90)");
+static_assert(offsetof(fs_uniform, gravity) == 16 && offsetof(fs_uniform, smoothing_radius) == 40 &&
+                  offsetof(fs_uniform, poly6_kernel_volume) == 72 && offsetof(fs_uniform, mouse_state) == 92 &&
+                  offsetof(fs_uniform, grid_w) == 104 && offsetof(fs_uniform, texture_size) == 112,
+              "SimulationUniform offsets");
+
+namespace {
+
+thread_local std::string g_err;
+
+fs_status fail(fs_status st, const std::string& msg) {
+    g_err = msg;
+    return st;
+}
+
+#define FS_HIP(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            return fail(e__ == hipErrorOutOfMemory ? FS_ERR_OOM : FS_ERR_DEVICE,                         \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                             \
+        }                                                                                                \
+    } while (0)
+
+const float PI_F = 3.14159265359f;   // funcs.wgsl:54 == std::f32::consts::PI in f32
+
+// Rust f32::powi (llvm.powi -> compiler-rt __powisf2): square-and-multiply.
+float powi_f32(float a, int b) {
+    float r = 1.0f;
+    const bool recip = b < 0;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0f / r : r;
+}
+
+// src/simulation.rs:140-141
+void grid_dims(const fs_settings& s, uint32_t* gw, uint32_t* gh) {
+    *gw = (uint32_t)((size_t)std::ceil(s.size.x / s.smoothing_radius) + 2);
+    *gh = (uint32_t)((size_t)std::ceil(s.size.y / s.smoothing_radius) + 2);
+}
+
+bool settings_valid(const fs_settings& s, std::string* why) {
+    if (s.particle_count <= 1) { *why = "particle_count <= 1 (reference panics in ilog2, src/simulation.rs:323-324)"; return false; }
+    if (!(s.smoothing_radius > 0.0f) || !std::isfinite(s.smoothing_radius)) { *why = "smoothing_radius must be finite and > 0"; return false; }
+    if (!(s.size.x > 0.0f) || !(s.size.y > 0.0f) || !std::isfinite(s.size.x) || !std::isfinite(s.size.y)) { *why = "size must be finite and > 0"; return false; }
+    if (!std::isfinite(s.particle_spacing)) { *why = "particle_spacing must be finite"; return false; }
+    const double gw = std::ceil((double)s.size.x / s.smoothing_radius) + 2, gh = std::ceil((double)s.size.y / s.smoothing_radius) + 2;
+    if (gw * gh >= 4294967295.0) { *why = "grid_w*grid_h does not fit u32 cell ids"; return false; }
+    if ((double)s.texture_size.x * s.texture_size.y >= 4294967295.0) { *why = "texture too large"; return false; }
+    return true;
+}
+
+template <class T>
+struct DevArray {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        if (count == 0) { p = nullptr; return hipSuccess; }
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct fs_sim {
+    fs_settings settings{};
+    fs_options opts{};
+    uint32_t n = 0, capacity = 0;
+    uint32_t grid_w = 0, grid_h = 0, ncell = 0;
+    uint32_t tick = 0;
+    fs_uniform uniform{};
+    hipStream_t stream = nullptr;
+    int device = 0;
+
+    // SoA state.  pos/vel: current state (cell order of the last step).  *_s: the
+    // cell-sorted snapshot the density/force passes read (Jacobi semantics).
+    DevArray<float2> pos, vel, pos_s, vel_s, pred;
+    DevArray<float> rho;
+    DevArray<uint32_t> key;
+    DevArray<fsd::u64> pairs;
+    DevArray<uint32_t> cs;          // dense cell-start table, ncell+1
+    DevArray<uint32_t> start_ref;   // reference start_indices (persistent, never cleared)
+    DevArray<float2> tex;           // force field
+    DevArray<unsigned char> work;   // gap worklist
+    DevArray<uint32_t> counter;
+    uint32_t work_cap = 0;
+    DevArray<fs_particle> aos;      // lazily allocated 32-byte view
+
+    bool profile = false;
+    hipEvent_t ev[FS_PASS_COUNT + 1] = {};
+    bool ev_ready = false;
+    double prof_ms[FS_PASS_COUNT] = {};
+    uint64_t prof_steps = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+
+    void release() {
+        pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release();
+        key.release(); pairs.release(); cs.release(); start_ref.release(); tex.release(); work.release();
+        counter.release(); aos.release();
+        if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
+namespace {
+
+void host_lattice(const fs_settings& s, fs_vec2 off, fs_particle* dst, size_t n) {
+    // src/simulation.rs:147-163 — f32 arithmetic exactly as written.
+    const uint32_t count = s.particle_count;
+    const float per_row = std::sqrt((float)count);
+    const float per_col = ((float)count - 1.0f) / per_row + 1.0f;
+    const size_t per_row_trunc = (size_t)per_row;
+    for (uint32_t i = 0; i < count && (size_t)i < n; ++i) {
+        const size_t col = (size_t)i % per_row_trunc;
+        fs_particle q;
+        std::memset(&q, 0, sizeof q);
+        q.position.x = ((float)col - per_row * 0.5f + 0.5f) * s.particle_spacing + off.x;
+        q.position.y = (std::floor((float)i / per_row) - per_col * 0.5f + 0.5f) * s.particle_spacing + off.y;
+        q.predicted_position = q.position;
+        dst[i] = q;
+    }
+}
+
+void host_uniform(const fs_settings& s, const fs_tick_settings& t, uint32_t tick, fs_uniform* u) {
+    // src/simulation.rs:470-497
+    const float h = s.smoothing_radius;
+    std::memset(u, 0, sizeof *u);
+    u->delta = t.delta;
+    u->particle_count = s.particle_count;
+    u->sqr_radius = h * h;
+    u->frame_time = tick;
+    u->gravity = t.gravity;
+    u->bounds = s.size;
+    u->mouse_pos = t.mouse_pos;
+    u->smoothing_radius = h;
+    u->particle_mass = t.mass;
+    u->pressure_constant = t.pressure_constant;
+    u->rest_density = t.rest_density;
+    u->damping_factor = t.damping_factor;
+    u->viscosity_coefficient = t.viscosity_coefficient;
+    u->surface_tension_treshold = t.surface_tension_treshold;
+    u->surface_tension_coefficient = t.surface_tension_coefficient;
+    const float h8 = powi_f32(h, 8);
+    u->poly6_kernel_volume = 4.0f / (PI_F * h8);
+    u->poly6_kernel_derivative = 24.0f / (PI_F * h8);
+    u->poly6_kernel_laplacian = 8.0f / (PI_F * h8);
+    u->spiky_kernel_derivative = 12.0f / (powi_f32(h, 4) * PI_F);
+    u->viscosity_kernel = 15.0f / (2.0f * PI_F * powi_f32(h, 3));
+    u->mouse_state = t.mouse_state;
+    u->mouse_force_radius = t.mouse_force_radius;
+    u->mouse_force_power = t.mouse_force_power;
+    grid_dims(s, &u->grid_w, &u->grid_h);
+    u->texture_size.x = (float)s.texture_size.x;
+    u->texture_size.y = (float)s.texture_size.y;
+}
+
+fsd::StepParams make_params(const fs_sim& s) {
+    const fs_uniform& u = s.uniform;
+    fsd::StepParams P;
+    std::memset(&P, 0, sizeof P);
+    P.n = s.n;
+    P.grid_w = s.grid_w; P.grid_h = s.grid_h; P.ncell = s.ncell;
+    P.dt = u.delta;
+    P.h = u.smoothing_radius;
+    P.sqr_radius = u.sqr_radius;
+    P.bounds_x = u.bounds.x; P.bounds_y = u.bounds.y;
+    P.bs_x = u.bounds.x * 0.5f; P.bs_y = u.bounds.y * 0.5f;
+    P.mass = u.particle_mass;
+    // funcs.wgsl:76 — `4.0 / (PI * pow(h, 8.0))`: loop-invariant, evaluated once per tick on
+    // the host with libm powf (the device pow is not correctly rounded).
+    P.poly6_norm = 4.0f / (PI_F * std::pow(u.smoothing_radius, 8.0f));
+    P.pressure_k = u.pressure_constant; P.rest_density = u.rest_density;
+    P.damping = u.damping_factor; P.visc_coeff = u.viscosity_coefficient;
+    P.spiky = u.spiky_kernel_derivative; P.visc_k = u.viscosity_kernel;
+    P.gx = u.gravity.x; P.gy = u.gravity.y;
+    P.mouse_x = u.mouse_pos.x; P.mouse_y = u.mouse_pos.y;
+    P.mouse_radius = u.mouse_force_radius; P.mouse_power = u.mouse_force_power;
+    P.mouse_state = u.mouse_state;
+    P.frame_time = u.frame_time;
+    P.tex_w = u.texture_size.x; P.tex_h = u.texture_size.y;
+    P.tex_w_u = s.settings.texture_size.x;   // u32(u.texture_size.x), compute.wgsl:129
+    P.tex_len = (uint32_t)s.tex.n;
+    P.ref_quirks = s.opts.ref_quirks;
+    return P;
+}
+
+fs_status ensure_events(fs_sim* s) {
+    if (!s->ev_ready) {
+        for (auto& e : s->ev) FS_HIP(hipEventCreate(&e));
+        s->ev_ready = true;
+    }
+    return FS_OK;
+}
+
+fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
+    s->tick += 1;                                              // src/simulation.rs:460
+    host_uniform(s->settings, *t, s->tick, &s->uniform);
+    s->uniform.particle_count = s->n;
+    const fsd::StepParams P = make_params(*s);
+    hipStream_t st = s->stream;
+    const bool prof = s->profile;
+    if (prof) { fs_status r = ensure_events(s); if (r != FS_OK) return r; }
+    if (s->n == 0) return FS_OK;
+
+    if (prof) FS_HIP(hipEventRecord(s->ev[0], st));
+    fsd::launch_predict_key(st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
+    if (prof) FS_HIP(hipEventRecord(s->ev[1], st));
+    if (s->opts.sort_mode == FS_SORT_BITONIC) {
+        fsd::launch_bitonic_sort(st, s->pairs.p, s->n);
+    } else {
+        return fail(FS_ERR_UNSUPPORTED, "sort_mode not built");
+    }
+    if (prof) FS_HIP(hipEventRecord(s->ev[2], st));
+    fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, s->key.p, s->cs.p,
+                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap);
+    if (prof) FS_HIP(hipEventRecord(s->ev[3], st));
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p);
+    if (prof) FS_HIP(hipEventRecord(s->ev[4], st));
+    fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho.p, s->cs.p, s->start_ref.p, s->pairs.p,
+                      s->tex.p, s->pos.p, s->vel.p);
+    if (prof) {
+        FS_HIP(hipEventRecord(s->ev[5], st));
+        FS_HIP(hipEventSynchronize(s->ev[5]));
+        for (int k = 0; k < FS_PASS_COUNT; ++k) {
+            float ms = 0.0f;
+            FS_HIP(hipEventElapsedTime(&ms, s->ev[k], s->ev[k + 1]));
+            s->prof_ms[k] += ms;
+        }
+        s->prof_steps += 1;
+    }
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_abi_version(void) { return FS_ABI_VERSION; }
+const char* fs_last_error(void) { return g_err.c_str(); }
+
+void fs_options_default(fs_options* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->device = 0;
+    o->sort_mode = FS_SORT_BITONIC;
+    o->ref_quirks = 1;
+}
+
+fs_status fs_create(const fs_settings* settings, int device, fs_sim** out) {
+    fs_options o;
+    fs_options_default(&o);
+    o.device = device;
+    return fs_create_ex(settings, &o, out);
+}
+
+fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_sim** out) {
+    if (!settings || !opts || !out) return fail(FS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::string why;
+    if (!settings_valid(*settings, &why)) return fail(FS_ERR_INVALID, why);
+    if (opts->sort_mode != FS_SORT_BITONIC && opts->sort_mode != FS_SORT_COUNTING)
+        return fail(FS_ERR_INVALID, "unknown sort_mode");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FS_ERR_DEVICE, "no HIP device: the engine has no CPU fallback");
+    if (opts->device < 0 || opts->device >= ndev) return fail(FS_ERR_INVALID, "device ordinal out of range");
+    FS_HIP(hipSetDevice(opts->device));
+
+    fs_sim* s = new (std::nothrow) fs_sim();
+    if (!s) return fail(FS_ERR_OOM, "host allocation failed");
+    s->settings = *settings;
+    s->opts = *opts;
+    s->device = opts->device;
+    s->n = settings->particle_count;
+    s->capacity = opts->capacity > s->n ? opts->capacity : s->n;
+    grid_dims(*settings, &s->grid_w, &s->grid_h);
+    s->ncell = s->grid_w * s->grid_h;
+    s->work_cap = s->ncell / 16u + 1024u;
+
+    auto bail = [&](fs_status st) { s->release(); delete s; return st; };
+#define FS_TRY(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e__ = (expr);                                                                              \
+        if (e__ != hipSuccess)                                                                                \
+            return bail(fail(e__ == hipErrorOutOfMemory ? FS_ERR_OOM : FS_ERR_DEVICE,                         \
+                             std::string(#expr) + ": " + hipGetErrorString(e__)));                            \
+    } while (0)
+
+    FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const size_t cap = s->capacity;
+    FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
+    FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->cs.alloc((size_t)s->ncell + 1));
+    FS_TRY(s->start_ref.alloc(s->ncell));
+    FS_TRY(s->tex.alloc((size_t)settings->texture_size.x * settings->texture_size.y));
+    FS_TRY(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
+    FS_TRY(s->counter.alloc(4));
+    FS_TRY(hipEventCreate(&s->t0));
+    FS_TRY(hipEventCreate(&s->t1));
+    // wgpu zero-initialises buffers: start_indices (simulation.rs:204-209), force field (:213-218)
+    FS_TRY(hipMemsetAsync(s->start_ref.p, 0, s->start_ref.n * sizeof(uint32_t), s->stream));
+    FS_TRY(hipMemsetAsync(s->cs.p, 0, s->cs.n * sizeof(uint32_t), s->stream));
+    if (s->tex.n) FS_TRY(hipMemsetAsync(s->tex.p, 0, s->tex.n * sizeof(float2), s->stream));
+    FS_TRY(hipMemsetAsync(s->counter.p, 0, 4 * sizeof(uint32_t), s->stream));
+    FS_TRY(hipMemsetAsync(s->rho.p, 0, cap * sizeof(float), s->stream));
+    FS_TRY(hipMemsetAsync(s->key.p, 0, cap * sizeof(uint32_t), s->stream));
+
+    // initial lattice (simulation.rs:147-163) -> AoS staging -> SoA
+    {
+        std::vector<fs_particle> host(s->n);
+        host_lattice(*settings, opts->initial_offset, host.data(), host.size());
+        FS_TRY(s->aos.alloc(cap));
+        FS_TRY(hipMemcpyAsync(s->aos.p, host.data(), host.size() * sizeof(fs_particle), hipMemcpyHostToDevice, s->stream));
+        fsd::launch_import_aos(s->stream, s->n, s->aos.p, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p);
+        FS_TRY(hipStreamSynchronize(s->stream));
+    }
+#undef FS_TRY
+    fs_tick_settings t0;
+    std::memset(&t0, 0, sizeof t0);
+    host_uniform(*settings, t0, 0, &s->uniform);
+    *out = s;
+    return FS_OK;
+}
+
+void fs_destroy(fs_sim* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    s->release();
+    delete s;
+}
+
+fs_status fs_step(fs_sim* s, const fs_tick_settings* t) {
+    if (!s || !t) return fail(FS_ERR_INVALID, "null argument");
+    FS_HIP(hipSetDevice(s->device));
+    return enqueue_step(s, t);
+}
+
+fs_status fs_sync(fs_sim* s) {
+    if (!s) return fail(FS_ERR_INVALID, "null argument");
+    FS_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+uint32_t fs_tick_count(const fs_sim* s) { return s ? s->tick : 0; }
+uint32_t fs_particle_count(const fs_sim* s) { return s ? s->n : 0; }
+void* fs_stream(const fs_sim* s) { return s ? (void*)s->stream : nullptr; }
+
+fs_status fs_grid_dims(const fs_sim* s, uint32_t* gw, uint32_t* gh) {
+    if (!s || !gw || !gh) return fail(FS_ERR_INVALID, "null argument");
+    *gw = s->grid_w; *gh = s->grid_h;
+    return FS_OK;
+}
+
+fs_status fs_particles_device(fs_sim* s, const fs_particle** out) {
+    if (!s || !out) return fail(FS_ERR_INVALID, "null argument");
+    FS_HIP(hipSetDevice(s->device));
+    if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
+    fsd::launch_export_aos(s->stream, s->n, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p, s->aos.p);
+    FS_HIP(hipGetLastError());
+    *out = s->aos.p;
+    return FS_OK;
+}
+
+fs_status fs_start_indices_device(fs_sim* s, const uint32_t** out, size_t* count) {
+    if (!s || !out) return fail(FS_ERR_INVALID, "null argument");
+    *out = s->start_ref.p;
+    if (count) *count = s->start_ref.n;
+    return FS_OK;
+}
+
+fs_status fs_get_uniform(const fs_sim* s, fs_uniform* out) {
+    if (!s || !out) return fail(FS_ERR_INVALID, "null argument");
+    *out = s->uniform;
+    return FS_OK;
+}
+
+fs_status fs_upload_force_field(fs_sim* s, const fs_vec2* field, uint32_t w, uint32_t h) {
+    if (!s || !field) return fail(FS_ERR_INVALID, "null argument");
+    if (w != s->settings.texture_size.x || h != s->settings.texture_size.y)
+        return fail(FS_ERR_INVALID, "force field dimensions differ from settings.texture_size");
+    FS_HIP(hipSetDevice(s->device));
+    FS_HIP(hipMemcpyAsync(s->tex.p, field, (size_t)w * h * sizeof(fs_vec2), hipMemcpyHostToDevice, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+fs_status fs_download_particles(fs_sim* s, fs_particle* dst, size_t n) {
+    if (!s || (!dst && n)) return fail(FS_ERR_INVALID, "null argument");
+    if (n > s->n) n = s->n;
+    const fs_particle* dev = nullptr;
+    fs_status r = fs_particles_device(s, &dev);
+    if (r != FS_OK) return r;
+    if (n) FS_HIP(hipMemcpyAsync(dst, dev, n * sizeof(fs_particle), hipMemcpyDeviceToHost, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+fs_status fs_upload_particles(fs_sim* s, const fs_particle* src, size_t n) {
+    if (!s || (!src && n)) return fail(FS_ERR_INVALID, "null argument");
+    if (n > s->n) n = s->n;   // ResizableBuffer::write trims oversize data (src/buffer.rs:71-75)
+    FS_HIP(hipSetDevice(s->device));
+    if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
+    if (n) FS_HIP(hipMemcpyAsync(s->aos.p, src, n * sizeof(fs_particle), hipMemcpyHostToDevice, s->stream));
+    fsd::launch_import_aos(s->stream, (uint32_t)n, s->aos.p, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p);
+    FS_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+fs_status fs_download_start_indices(fs_sim* s, uint32_t* dst, size_t n) {
+    if (!s || (!dst && n)) return fail(FS_ERR_INVALID, "null argument");
+    if (n > s->start_ref.n) n = s->start_ref.n;
+    FS_HIP(hipSetDevice(s->device));
+    if (n) FS_HIP(hipMemcpyAsync(dst, s->start_ref.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+fs_status fs_upload_start_indices(fs_sim* s, const uint32_t* src, size_t n) {
+    if (!s || (!src && n)) return fail(FS_ERR_INVALID, "null argument");
+    if (n > s->start_ref.n) n = s->start_ref.n;
+    FS_HIP(hipSetDevice(s->device));
+    if (n) FS_HIP(hipMemcpyAsync(s->start_ref.p, src, n * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+fs_status fs_reference_lattice(const fs_settings* settings, fs_vec2 offset, fs_particle* dst, size_t n) {
+    if (!settings || (!dst && n)) return fail(FS_ERR_INVALID, "null argument");
+    if (settings->particle_count == 0) return FS_OK;
+    host_lattice(*settings, offset, dst, n);
+    return FS_OK;
+}
+
+size_t fs_sort_schedule(uint32_t particle_count, fs_sort_step* dst, size_t cap) {
+    // src/simulation.rs:323-347
+    if (particle_count <= 1) return 0;
+    uint32_t p2 = 1, stages = 0;
+    while (p2 < particle_count) { p2 <<= 1; ++stages; }
+    size_t k = 0;
+    for (uint32_t stage = 0; stage < stages; ++stage)
+        for (uint32_t step = 0; step <= stage; ++step, ++k)
+            if (dst && k < cap) {
+                const uint32_t gw = 1u << (stage - step);
+                dst[k] = fs_sort_step{gw, 2 * gw - 1, step, particle_count};
+            }
+    return k;
+}
+
+fs_status fs_build_uniform(const fs_settings* settings, const fs_tick_settings* tick, uint32_t tick_count,
+                           fs_uniform* out) {
+    if (!settings || !tick || !out) return fail(FS_ERR_INVALID, "null argument");
+    host_uniform(*settings, *tick, tick_count, out);
+    return FS_OK;
+}
+
+fs_status fs_profile_enable(fs_sim* s, int enable) {
+    if (!s) return fail(FS_ERR_INVALID, "null argument");
+    s->profile = enable != 0;
+    return FS_OK;
+}
+
+fs_status fs_profile_read(fs_sim* s, double ms[FS_PASS_COUNT], uint64_t* steps, int reset) {
+    if (!s || !ms) return fail(FS_ERR_INVALID, "null argument");
+    for (int k = 0; k < FS_PASS_COUNT; ++k) ms[k] = s->prof_ms[k];
+    if (steps) *steps = s->prof_steps;
+    if (reset) { for (auto& m : s->prof_ms) m = 0.0; s->prof_steps = 0; }
+    return FS_OK;
+}
+
+fs_status fs_timed_steps(fs_sim* s, const fs_tick_settings* t, uint32_t steps, double* ms_total) {
+    if (!s || !t || !ms_total) return fail(FS_ERR_INVALID, "null argument");
+    FS_HIP(hipSetDevice(s->device));
+    FS_HIP(hipEventRecord(s->t0, s->stream));
+    for (uint32_t k = 0; k < steps; ++k) {
+        fs_status r = enqueue_step(s, t);
+        if (r != FS_OK) return r;
+    }
+    FS_HIP(hipEventRecord(s->t1, s->stream));
+    FS_HIP(hipEventSynchronize(s->t1));
+    float ms = 0.0f;
+    FS_HIP(hipEventElapsedTime(&ms, s->t0, s->t1));
+    *ms_total = ms;
+    return FS_OK;
+}
+
+}  // extern "C"

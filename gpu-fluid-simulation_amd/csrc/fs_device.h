@@ -1,0 +1,81 @@
+// fs_device.h — parameters and device helpers shared by the HIP kernels.
+//
+// Float contract: every expression below is written in the association the
+// reference shaders use and the TU is compiled with -ffp-contract=off, so with
+// IEEE-correct +,-,*,/,sqrt (hipcc default: correctly rounded f32 divide/sqrt)
+// the kernels reproduce the CPU oracle bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fsd {
+
+typedef unsigned long long u64;
+
+// Per-tick parameters, passed by value (replaces the 120-byte uniform buffer,
+// src/uniform.rs:93-95; contents follow src/simulation.rs:470-497).
+struct StepParams {
+    uint32_t n;            // particle_count
+    uint32_t grid_w, grid_h, ncell;
+    float dt;              // delta
+    float h;               // smoothing_radius
+    float sqr_radius;      // h*h
+    float bounds_x, bounds_y;
+    float bs_x, bs_y;      // bounds * 0.5
+    float mass;
+    float poly6_norm;      // 4/(PI*pow(h,8)) — funcs.wgsl:76, evaluated once on the host
+    float pressure_k, rest_density;
+    float damping, visc_coeff;
+    float spiky, visc_k;   // spiky_kernel_derivative, viscosity_kernel (simulation.rs:489-490)
+    float gx, gy;
+    float mouse_x, mouse_y, mouse_radius, mouse_power;
+    int32_t mouse_state;
+    uint32_t frame_time;
+    float tex_w, tex_h;
+    uint32_t tex_w_u, tex_len;
+    int32_t ref_quirks;
+};
+
+// WGSL f32 -> u32 conversion: saturating, NaN -> 0.
+__device__ __forceinline__ uint32_t f32_to_u32_sat(float x) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
+__device__ __forceinline__ float sign_f32(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+// compute.wgsl:16-26
+__device__ __forceinline__ float2 predict_pos(const StepParams& P, float2 pos, float2 vel) {
+    float2 pr;
+    pr.x = pos.x + vel.x * P.dt;
+    pr.y = pos.y + vel.y * P.dt;
+    if (fabsf(pr.x) > P.bs_x) pr.x = P.bs_x * sign_f32(pr.x);
+    if (fabsf(pr.y) > P.bs_y) pr.y = P.bs_y * sign_f32(pr.y);
+    return pr;
+}
+
+// funcs.wgsl:212-214
+__device__ __forceinline__ void xy_of_point(const StepParams& P, float2 pt, uint32_t* cx, uint32_t* cy) {
+    const float fx = floorf(__fdiv_rn(pt.x + P.bs_x, P.h));
+    const float fy = floorf(__fdiv_rn(pt.y + P.bs_y, P.h));
+    *cx = f32_to_u32_sat(fx) + 1u;
+    *cy = f32_to_u32_sat(fy) + 1u;
+}
+
+// funcs.wgsl:206-218
+__device__ __forceinline__ uint32_t cell_of_point(const StepParams& P, float2 pt) {
+    uint32_t cx, cy;
+    xy_of_point(P, pt, &cx, &cy);
+    return cy * P.grid_w + cx;
+}
+
+// funcs.wgsl:129-149
+__device__ __forceinline__ float rand_f32(uint32_t* st) {
+    uint32_t x = *st;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    *st = x;
+    return __fdiv_rn((float)x, 4294967296.0f);
+}
+
+}  // namespace fsd

@@ -1,0 +1,31 @@
+// fs_kernels.h — host-side launchers of the HIP kernels (kernels_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fs_device.h"
+
+namespace fsd {
+
+void launch_predict_key(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, u64* pairs,
+                        uint32_t* gap_counter);
+void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
+                    float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
+                    void* work, uint32_t* counter, uint32_t work_cap);
+void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
+                    const uint32_t* start_ref, const u64* pairs, float* rho);
+void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
+                  const float* rho, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
+                  float2* pos_out, float2* vel_out);
+void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
+                       const float* rho, const uint32_t* key, void* out);
+void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, float2* pred, float2* vel, float* rho,
+                       uint32_t* key);
+size_t gap_entry_size();
+
+// Bitonic network of sort.wgsl:27-51 / simulation.rs:323-347 on (key<<32 | index) pairs.
+// Returns the number of kernel launches issued.
+int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n);
+
+}  // namespace fsd

@@ -1,0 +1,363 @@
+// kernels_step.hip — the non-sort passes of the SPH step as CDNA4 (gfx950) kernels.
+//
+// Device state is SoA (float2 pos / vel / pred, f32 density): coalesced 8-byte
+// per-lane streams instead of the reference's 32-byte AoS records.  Pass map:
+//   k_predict_key   = predict_next_position + create_spatial_lookup (compute.wgsl:8-42)
+//   k_reorder       = payload gather after the (key,index) sort + compute_start_indices
+//                     (compute.wgsl:45-56) + dense cell-start table
+//   k_density       = calculate_density (compute.wgsl:59-74, funcs.wgsl:157-203)
+//   k_force         = move_particle + both force sweeps fused (compute.wgsl:79-299)
+#include "fs_device.h"
+#include "fs_kernels.h"
+
+namespace fsd {
+
+#define FS_BLOCK 256
+
+// ---------------------------------------------------------------- predict + key
+__global__ __launch_bounds__(FS_BLOCK) void k_predict_key(StepParams P, const float2* __restrict__ pos,
+                                                          const float2* __restrict__ vel, u64* __restrict__ pairs,
+                                                          uint32_t* __restrict__ gap_counter) {
+    const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i == 0) *gap_counter = 0;   // consumed by k_reorder / k_fill_gaps later in the stream
+    if (i >= P.n) return;
+    const float2 pr = predict_pos(P, pos[i], vel[i]);
+    const uint32_t key = cell_of_point(P, pr);
+    pairs[i] = ((u64)key << 32) | (u64)i;
+}
+
+// --------------------------------------------------- dense cell-start table fill
+// cs[c] = index of the first sorted particle whose key is >= c (c in [0, ncell]).
+// Short gaps are written by the boundary lane; long gaps go to a worklist.
+#define FS_GAP_INLINE 16u
+#define FS_GAP_CHUNK 16384u
+
+struct GapEntry { uint32_t begin, end, value; };
+
+__device__ __forceinline__ void fill_cells(uint32_t* __restrict__ cs, uint32_t begin, uint32_t end, uint32_t value,
+                                           GapEntry* __restrict__ work, uint32_t* __restrict__ counter,
+                                           uint32_t work_cap) {
+    if (end <= begin) return;
+    if (end - begin <= FS_GAP_INLINE) {
+        for (uint32_t c = begin; c < end; ++c) cs[c] = value;
+        return;
+    }
+    for (uint32_t b = begin; b < end; b += FS_GAP_CHUNK) {
+        const uint32_t e = (end - b > FS_GAP_CHUNK) ? b + FS_GAP_CHUNK : end;
+        const uint32_t slot = atomicAdd(counter, 1u);
+        if (slot < work_cap) {
+            work[slot] = GapEntry{b, e, value};
+        } else {
+            for (uint32_t c = b; c < e; ++c) cs[c] = value;   // never expected: capacity covers the worst case
+        }
+    }
+}
+
+__global__ __launch_bounds__(FS_BLOCK) void k_fill_gaps(uint32_t* __restrict__ cs, const GapEntry* __restrict__ work,
+                                                        const uint32_t* __restrict__ counter, uint32_t work_cap) {
+    uint32_t count = *counter;
+    if (count > work_cap) count = work_cap;
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const GapEntry g = work[e];
+        for (uint32_t c = g.begin + threadIdx.x; c < g.end; c += FS_BLOCK) cs[c] = g.value;
+    }
+}
+
+// -------------------------------------------------------------------- reorder
+// Gathers the payload into cell order (the reference swaps whole 32-byte records
+// inside the sort, sort.wgsl:44-50; sorting (key,index) pairs and gathering once
+// gives the identical arrangement because the network only looks at keys).
+__global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* __restrict__ pairs,
+                                                      const float2* __restrict__ pos_in,
+                                                      const float2* __restrict__ vel_in, float2* __restrict__ pos_s,
+                                                      float2* __restrict__ vel_s, float2* __restrict__ pred_s,
+                                                      uint32_t* __restrict__ key_s, uint32_t* __restrict__ cs,
+                                                      uint32_t* __restrict__ start_ref, GapEntry* __restrict__ work,
+                                                      uint32_t* __restrict__ counter, uint32_t work_cap) {
+    const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i >= P.n) return;
+    const u64 pr = pairs[i];
+    const uint32_t key = (uint32_t)(pr >> 32);
+    const uint32_t src = (uint32_t)pr;
+    const float2 p = pos_in[src];
+    const float2 v = vel_in[src];
+    pos_s[i] = p;
+    vel_s[i] = v;
+    pred_s[i] = predict_pos(P, p, v);   // same expression as k_predict_key -> same bits
+    key_s[i] = key;
+
+    const uint32_t kc = key < P.ncell ? key : P.ncell;   // clamp for table writes only
+    if (i == 0) {
+        if (!P.ref_quirks && key < P.ncell) start_ref[key] = 0;   // compute.wgsl:50 skips index 0
+        fill_cells(cs, 0u, kc + 1u > P.ncell + 1u ? P.ncell + 1u : kc + 1u, 0u, work, counter, work_cap);
+    } else {
+        const uint32_t prev = (uint32_t)(pairs[i - 1] >> 32);
+        if (key != prev) {
+            if (key < P.ncell) start_ref[key] = i;                // compute.wgsl:53-55
+            const uint32_t pc = prev < P.ncell ? prev : P.ncell;
+            fill_cells(cs, pc + 1u, kc + 1u, i, work, counter, work_cap);
+        }
+    }
+    if (i == P.n - 1) fill_cells(cs, kc + 1u, P.ncell + 1u, P.n, work, counter, work_cap);
+}
+
+// ------------------------------------------------------------ neighbour ranges
+// Cells (cx-1..cx+1, y) are consecutive ids, and particles are in id order, so a
+// row of the 3x3 sweep is ONE contiguous index range [cs[id_lo], cs[id_lo+3]).
+// Visiting it ascending is exactly the reference order (offset_x inner, index
+// ascending: funcs.wgsl:161-199).
+//
+// Quirk: the cell of sorted index 0 never gets its start written
+// (compute.wgsl:50), so the reference walks it from a stale start v.  Its
+// particles are [0,cnt); the walk sees [min(v,cnt), cnt).  Any row range that
+// begins at index 0 begins with that cell, so `lo == 0 -> lo = lo_fix`.
+__device__ __forceinline__ uint32_t quirk_lo_fix(const StepParams& P, const u64* __restrict__ pairs,
+                                                 const uint32_t* __restrict__ cs,
+                                                 const uint32_t* __restrict__ start_ref) {
+    if (!P.ref_quirks) return 0u;
+    const uint32_t cmin = (uint32_t)(pairs[0] >> 32);
+    if (cmin >= P.ncell) return 0u;
+    const uint32_t v = start_ref[cmin];
+    const uint32_t cnt = cs[cmin + 1];
+    return v < cnt ? v : cnt;
+}
+
+__device__ __forceinline__ bool row_range(const StepParams& P, const uint32_t* __restrict__ cs, uint32_t cx,
+                                          uint32_t y, uint32_t lo_fix, uint32_t* lo, uint32_t* hi) {
+    if (y >= P.grid_h) return false;             // id >= ncell: OOB start_indices read -> nothing
+    const uint32_t id_lo = y * P.grid_w + cx - 1u;
+    if (id_lo >= P.ncell) return false;
+    uint32_t id_hi = id_lo + 3u;
+    if (id_hi > P.ncell) id_hi = P.ncell;
+    uint32_t a = cs[id_lo];
+    const uint32_t b = cs[id_hi];
+    if (a == 0u) a = lo_fix;
+    *lo = a;
+    *hi = b;
+    return a < b;
+}
+
+// -------------------------------------------------------------------- density
+__global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2* __restrict__ pred,
+                                                      const uint32_t* __restrict__ cs,
+                                                      const uint32_t* __restrict__ start_ref,
+                                                      const u64* __restrict__ pairs, float* __restrict__ rho_out) {
+    const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i >= P.n) return;
+    const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
+    const float2 me = pred[i];
+    uint32_t cx, cy;
+    xy_of_point(P, me, &cx, &cy);
+    const float h2 = P.h * P.h;     // funcs.wgsl:73
+    float rho = 0.0f;
+#pragma unroll 1
+    for (int oy = -1; oy <= 1; ++oy) {
+        uint32_t lo, hi;
+        if (!row_range(P, cs, cx, cy + (uint32_t)oy, lo_fix, &lo, &hi)) continue;
+        for (uint32_t k = lo; k < hi; ++k) {
+            const float2 q = pred[k];
+            const float dx = q.x - me.x, dy = q.y - me.y;
+            const float r2 = dx * dx + dy * dy;
+            float kern = 0.0f;
+            if (!(r2 > h2)) {
+                const float diff = h2 - r2;
+                kern = P.poly6_norm * diff * diff * diff;       // funcs.wgsl:77
+            }
+            rho += P.mass * kern * 1.0f;                        // funcs.wgsl:192
+        }
+    }
+    rho = fmaxf(rho, 1.19209290e-07f);                          // funcs.wgsl:202
+    rho_out[i] = fmaxf(rho, 0.1f);                              // compute.wgsl:70
+}
+
+// ---------------------------------------------------------- force + integrate
+__global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* __restrict__ pos_s,
+                                                    const float2* __restrict__ vel_s,
+                                                    const float2* __restrict__ pred, const float* __restrict__ rho,
+                                                    const uint32_t* __restrict__ cs,
+                                                    const uint32_t* __restrict__ start_ref,
+                                                    const u64* __restrict__ pairs, const float2* __restrict__ tex,
+                                                    float2* __restrict__ pos_out, float2* __restrict__ vel_out) {
+    const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i >= P.n) return;
+    const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
+    const float2 me = pred[i];
+    const float2 mv = vel_s[i];
+    const float mrho = rho[i];
+    const float pressure = P.pressure_k * (mrho - P.rest_density);      // funcs.wgsl:152-154
+    uint32_t seed = i * 12u + P.frame_time * 69u;                      // compute.wgsl:161
+    uint32_t cx, cy;
+    xy_of_point(P, me, &cx, &cy);
+    float fpx = 0.0f, fpy = 0.0f, fvx = 0.0f, fvy = 0.0f;
+    const float h = P.h;
+#pragma unroll 1
+    for (int oy = -1; oy <= 1; ++oy) {
+        uint32_t lo, hi;
+        if (!row_range(P, cs, cx, cy + (uint32_t)oy, lo_fix, &lo, &hi)) continue;
+        for (uint32_t k = lo; k < hi; ++k) {
+            if (k == i) continue;                                       // compute.wgsl:195,271
+            const float2 q = pred[k];
+            const float ox = q.x - me.x, oyv = q.y - me.y;
+            const float r2 = ox * ox + oyv * oyv;
+            if (r2 > P.sqr_radius) continue;                            // :202,278
+            const float dst = __fsqrt_rn(r2);
+            const float nrho = rho[k];
+            const float2 nv = vel_s[k];
+            // pressure (compute.wgsl:209-223)
+            float dx, dy;
+            if (dst == 0.0f) {
+                const float rx = rand_f32(&seed);
+                const float ry = rand_f32(&seed);
+                const float len = __fsqrt_rn(rx * rx + ry * ry);
+                dx = __fdiv_rn(rx, len);
+                dy = __fdiv_rn(ry, len);
+            } else {
+                dx = __fdiv_rn(ox, dst);
+                dy = __fdiv_rn(oyv, dst);
+            }
+            const float npress = P.pressure_k * (nrho - P.rest_density);
+            const float kern = (dst <= h) ? (-(h - dst)) * P.spiky : 0.0f;   // funcs.wgsl:101-109
+            const float shared = (pressure + npress) * 0.5f;
+            fpx += __fdiv_rn(dx * kern * shared, nrho);
+            fpy += __fdiv_rn(dy * kern * shared, nrho);
+            // viscosity (compute.wgsl:283-288, funcs.wgsl:112-123)
+            float kv = 0.0f;
+            if (dst <= h) {
+                if (dst == 0.0f) {
+                    kv = P.visc_k;
+                } else {
+                    kv = P.visc_k * ((__fdiv_rn(-(dst * dst * dst), 2.0f * h * h * h)) + (__fdiv_rn(dst * dst, h * h)) +
+                                     (__fdiv_rn(h, 2.0f * dst)) - 1.0f);
+                }
+            }
+            fvx += __fdiv_rn(nv.x - mv.x, nrho) * kv;
+            fvy += __fdiv_rn(nv.y - mv.y, nrho) * kv;
+        }
+    }
+    fvx = fvx * P.visc_coeff;                                           // compute.wgsl:298
+    fvy = fvy * P.visc_coeff;
+
+    // integrate (compute.wgsl:93-153)
+    float2 v = mv;
+    float2 p = pos_s[i];
+    const float ax = fpx + fvx, ay = fpy + fvy;
+    v.x += __fdiv_rn(ax, mrho) * P.dt;
+    v.y += __fdiv_rn(ay, mrho) * P.dt;
+    v.x += P.gx * P.dt;
+    v.y += P.gy * P.dt;
+    if (P.mouse_state != 0) {
+        const float dx = P.mouse_x - me.x, dy = P.mouse_y - me.y;
+        const float dist = __fsqrt_rn(dx * dx + dy * dy);
+        if (dist <= P.mouse_radius) {
+            const float dirx = __fdiv_rn(__fdiv_rn(dx, dist), dist);
+            const float diry = __fdiv_rn(__fdiv_rn(dy, dist), dist);
+            const float ratio = __fdiv_rn(dist, P.mouse_radius);
+            v.x += dirx * P.mouse_power * (float)P.mouse_state * ratio;
+            v.y += diry * P.mouse_power * (float)P.mouse_state * ratio;
+        }
+    }
+    if (!(v.x == v.x && v.y == v.y)) { v.x = 0.0f; v.y = 0.0f; }
+    const float speed = __fsqrt_rn(v.x * v.x + v.y * v.y);
+    if (speed > 500.0f) {
+        v.x = __fdiv_rn(v.x, speed) * 500.0f;
+        v.y = __fdiv_rn(v.y, speed) * 500.0f;
+    }
+    p.x += v.x * P.dt;
+    p.y += v.y * P.dt;
+
+    const float uvx = (__fdiv_rn(me.x, P.bounds_x) * 1.0f) + 0.5f;      // compute.wgsl:127
+    const float uvy = (__fdiv_rn(me.y, P.bounds_y) * 1.0f) + 0.5f;
+    const uint32_t px = f32_to_u32_sat(uvx * P.tex_w);
+    const uint32_t py = f32_to_u32_sat(uvy * P.tex_h);
+    const uint32_t tix = py * P.tex_w_u + px;
+    float2 force = make_float2(0.0f, 0.0f);
+    if (tix < P.tex_len) force = tex[tix];
+    if (force.x != 0.0f || force.y != 0.0f) {                           // compute.wgsl:131-140
+        const float p2wx = __fdiv_rn(P.bounds_x * 2.0f, P.tex_w);
+        const float p2wy = __fdiv_rn(P.bounds_y * 2.0f, P.tex_h);
+        const float fwx = force.x * p2wx, fwy = force.y * p2wy;
+        const float len = __fsqrt_rn(force.x * force.x + force.y * force.y);
+        const float nx = __fdiv_rn(force.x, len), ny = __fdiv_rn(force.y, len);
+        p.x += fwx;
+        p.y += fwy;
+        const float vn = v.x * nx + v.y * ny;
+        v.x -= (1.0f - P.damping) * vn * nx;
+        v.y -= (1.0f - P.damping) * vn * ny;
+    }
+    if (fabsf(p.x) > P.bs_x) { p.x = P.bs_x * sign_f32(p.x); v.x *= -1.0f * P.damping; }
+    if (fabsf(p.y) > P.bs_y) { p.y = P.bs_y * sign_f32(p.y); v.y *= -1.0f * P.damping; }
+    pos_out[i] = p;
+    vel_out[i] = v;
+}
+
+// --------------------------------------------------------------- AoS <-> SoA
+struct AosParticle { float2 position, predicted, velocity; float density; uint32_t grid; };
+
+__global__ __launch_bounds__(FS_BLOCK) void k_export_aos(uint32_t n, const float2* __restrict__ pos,
+                                                         const float2* __restrict__ pred,
+                                                         const float2* __restrict__ vel,
+                                                         const float* __restrict__ rho,
+                                                         const uint32_t* __restrict__ key,
+                                                         AosParticle* __restrict__ out) {
+    const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    AosParticle a;
+    a.position = pos[i]; a.predicted = pred[i]; a.velocity = vel[i]; a.density = rho[i]; a.grid = key[i];
+    out[i] = a;
+}
+
+__global__ __launch_bounds__(FS_BLOCK) void k_import_aos(uint32_t n, const AosParticle* __restrict__ in,
+                                                         float2* __restrict__ pos, float2* __restrict__ pred,
+                                                         float2* __restrict__ vel, float* __restrict__ rho,
+                                                         uint32_t* __restrict__ key) {
+    const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const AosParticle a = in[i];
+    pos[i] = a.position; pred[i] = a.predicted; vel[i] = a.velocity; rho[i] = a.density; key[i] = a.grid;
+}
+
+// ------------------------------------------------------------------ launchers
+static inline uint32_t nblk(uint32_t n) { return (n + FS_BLOCK - 1) / FS_BLOCK; }
+
+void launch_predict_key(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, u64* pairs,
+                        uint32_t* gap_counter) {
+    hipLaunchKernelGGL(k_predict_key, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pos, vel, pairs, gap_counter);
+}
+
+void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
+                    float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
+                    void* work, uint32_t* counter, uint32_t work_cap) {
+    hipLaunchKernelGGL(k_reorder, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pairs, pos_in, vel_in, pos_s, vel_s,
+                       pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap);
+    hipLaunchKernelGGL(k_fill_gaps, dim3(1024), dim3(FS_BLOCK), 0, st, cs, (const GapEntry*)work, counter, work_cap);
+}
+
+void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
+                    const uint32_t* start_ref, const u64* pairs, float* rho) {
+    hipLaunchKernelGGL(k_density, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, rho);
+}
+
+void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
+                  const float* rho, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
+                  float2* pos_out, float2* vel_out) {
+    hipLaunchKernelGGL(k_force, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho, cs, start_ref,
+                       pairs, tex, pos_out, vel_out);
+}
+
+void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
+                       const float* rho, const uint32_t* key, void* out) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_export_aos, dim3(nblk(n)), dim3(FS_BLOCK), 0, st, n, pos, pred, vel, rho, key,
+                       (AosParticle*)out);
+}
+
+void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, float2* pred, float2* vel, float* rho,
+                       uint32_t* key) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_import_aos, dim3(nblk(n)), dim3(FS_BLOCK), 0, st, n, (const AosParticle*)in, pos, pred, vel,
+                       rho, key);
+}
+
+size_t gap_entry_size() { return sizeof(GapEntry); }
+
+}  // namespace fsd

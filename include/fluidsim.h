@@ -1,0 +1,224 @@
+/*
+ * fluidsim.h — C ABI of the MI355X-native SPH fluid-step engine.
+ *
+ * This is the drop-in boundary for the reference's per-tick hot path
+ * (rookieCookies/gpu-fluid-simulation).  Every entry point cites the reference
+ * interface it replaces as file:line relative to the reference tree.  Plain
+ * pointers and sizes only; no C++/torch types cross this boundary; nothing here
+ * throws or aborts — every call returns an fs_status.
+ *
+ * Reference surface mirrored here:
+ *   FluidSimulation::new      src/simulation.rs:139-455
+ *   FluidSimulation::tick     src/simulation.rs:459-539
+ *   accessors                 src/simulation.rs:542-564
+ *   ParticleInstance (32 B)   src/simulation.rs:126-135, funcs.wgsl:1-8
+ *   SimulationUniform (120 B) src/simulation.rs:53-90,   funcs.wgsl:17-51
+ *   SimulationSettings        src/simulation.rs:95-104
+ *   TickSettings              src/simulation.rs:107-122
+ *   ResizableBuffer<T>/SSBO<T> src/buffer.rs:9-173
+ */
+#ifndef FLUIDSIM_H
+#define FLUIDSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ status */
+typedef enum fs_status {
+    FS_OK = 0,
+    FS_ERR_INVALID = 1,      /* bad argument; N <= 1 (reference panics: simulation.rs:323-324) */
+    FS_ERR_DEVICE = 2,       /* HIP runtime error (message in fs_last_error) */
+    FS_ERR_OOM = 3,          /* device or host allocation failed */
+    FS_ERR_UNSUPPORTED = 4,  /* option combination not built */
+    FS_ERR_COMM = 5          /* RCCL error */
+} fs_status;
+
+/* ------------------------------------------------------------------- PODs */
+typedef struct fs_vec2 { float x, y; } fs_vec2;
+typedef struct fs_vec3 { float x, y, z; } fs_vec3;
+typedef struct fs_uvec2 { uint32_t x, y; } fs_uvec2;
+
+/* SimulationSettings — src/simulation.rs:95-104 (same fields, same order). */
+typedef struct fs_settings {
+    uint32_t particle_count;
+    float particle_spacing;
+    float smoothing_radius;
+    fs_vec2 size;
+    fs_uvec2 texture_size;
+} fs_settings;
+
+/* TickSettings — src/simulation.rs:107-122 (same fields, same order). */
+typedef struct fs_tick_settings {
+    float delta;
+    fs_vec2 gravity;
+    float mass;
+    float pressure_constant;
+    float rest_density;
+    float damping_factor;
+    float viscosity_coefficient;
+    float surface_tension_treshold;     /* sic — spelling follows the reference */
+    float surface_tension_coefficient;
+    float mouse_force_radius;
+    float mouse_force_power;
+    fs_vec2 mouse_pos;
+    int32_t mouse_state;
+} fs_tick_settings;
+
+/* ParticleInstance — src/simulation.rs:126-135; 32 bytes, offsets 0/8/16/24/28. */
+typedef struct fs_particle {
+    fs_vec2 position;
+    fs_vec2 predicted_position;
+    fs_vec2 velocity;
+    float density;
+    uint32_t grid;
+} fs_particle;
+
+/* SimulationUniform — src/simulation.rs:53-90; 120 bytes. */
+typedef struct fs_uniform {
+    float delta;
+    uint32_t particle_count;
+    float sqr_radius;
+    uint32_t frame_time;
+    fs_vec2 gravity;
+    fs_vec2 bounds;
+    fs_vec2 mouse_pos;
+    float smoothing_radius;
+    float particle_mass;
+    float pressure_constant;
+    float rest_density;
+    float damping_factor;
+    float viscosity_coefficient;
+    float surface_tension_treshold;
+    float surface_tension_coefficient;
+    float poly6_kernel_volume;
+    float poly6_kernel_derivative;
+    float poly6_kernel_laplacian;
+    float spiky_kernel_derivative;
+    float viscosity_kernel;
+    int32_t mouse_state;
+    float mouse_force_radius;
+    float mouse_force_power;
+    uint32_t grid_w;
+    uint32_t grid_h;
+    fs_vec2 texture_size;
+} fs_uniform;
+
+/* SortUniform payload — src/simulation.rs:40-50 (without the 240-byte pad). */
+typedef struct fs_sort_step {
+    uint32_t group_width;
+    uint32_t group_height;
+    uint32_t step_index;
+    uint32_t num_values;
+} fs_sort_step;
+
+/* Build-defined options (NOT in the reference; defaults reproduce the reference). */
+typedef enum fs_sort_mode {
+    FS_SORT_BITONIC = 0,   /* reference network (sort.wgsl:27-51): bit-exact permutation */
+    FS_SORT_COUNTING = 1   /* O(N) cell counting sort; stable within a cell */
+} fs_sort_mode;
+
+typedef struct fs_options {
+    int32_t device;            /* HIP device ordinal */
+    int32_t sort_mode;         /* fs_sort_mode */
+    int32_t ref_quirks;        /* 1 = reproduce compute.wgsl:49-55 stale cell-start behaviour */
+    int32_t reserved0;
+    fs_vec2 initial_offset;    /* translation added to the reference lattice (dam-break scene) */
+    uint32_t capacity;         /* particle slots to allocate (0 = particle_count); multi-GPU slabs */
+    uint32_t reserved1;
+} fs_options;
+
+typedef struct fs_sim fs_sim;       /* opaque: one simulation, one HIP stream */
+typedef struct fs_buffer fs_buffer; /* opaque: ResizableBuffer<T> */
+
+/* ------------------------------------------------------------- lifecycle */
+/* FluidSimulation::new (src/simulation.rs:139): builds the reference lattice
+ * (:147-163), zeroed start_indices (:204-209) and force field (:213-218).
+ * device = HIP ordinal.  N <= 1 -> FS_ERR_INVALID (reference: ilog2(0) panic). */
+fs_status fs_create(const fs_settings* settings, int device, fs_sim** out);
+fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_sim** out);
+void fs_options_default(fs_options* opts);
+/* Drop of FluidSimulation (Renderer owns it: src/renderer.rs:31). */
+void fs_destroy(fs_sim* sim);
+
+/* --------------------------------------------------------------- stepping */
+/* FluidSimulation::tick (src/simulation.rs:459-539).  Pre-increments `tick`,
+ * builds the 120-byte uniform (:470-497) and enqueues the whole pass chain on
+ * the simulation's stream.  Non-blocking, like the reference (which only
+ * records into a CommandEncoder; submit happens at src/main.rs:226). */
+fs_status fs_step(fs_sim* sim, const fs_tick_settings* tick);
+/* device.poll(Wait) equivalent (src/main.rs:79). */
+fs_status fs_sync(fs_sim* sim);
+/* pub tick: u32 (src/simulation.rs:12). */
+uint32_t fs_tick_count(const fs_sim* sim);
+uint32_t fs_particle_count(const fs_sim* sim);
+/* grid_w / grid_h (src/simulation.rs:140-141). */
+fs_status fs_grid_dims(const fs_sim* sim, uint32_t* grid_w, uint32_t* grid_h);
+/* The HIP stream the pass chain runs on (hipStream_t as void*). */
+void* fs_stream(const fs_sim* sim);
+
+/* ------------------------------------------- data the renderer consumes */
+/* simulation_bg binding 0 (src/simulation.rs:552-559; fluid_shader.wgsl:38-75):
+ * cell-sorted 32-byte AoS records, device pointer.  The engine keeps SoA state;
+ * the AoS view is materialised on the stream by this call. */
+fs_status fs_particles_device(fs_sim* sim, const fs_particle** out);
+/* simulation_bg binding 1: start_indices u32[grid_w*grid_h] (persistent, never cleared). */
+fs_status fs_start_indices_device(fs_sim* sim, const uint32_t** out, size_t* count);
+/* simulation_settings_bg (src/simulation.rs:552-554): last uniform written by fs_step. */
+fs_status fs_get_uniform(const fs_sim* sim, fs_uniform* out);
+/* force_field_texture() (src/simulation.rs:562-564) + queue.write_buffer (src/renderer.rs:497-502). */
+fs_status fs_upload_force_field(fs_sim* sim, const fs_vec2* field, uint32_t w, uint32_t h);
+
+/* Host copies (checkpoint / tests).  Blocking.  n = number of records. */
+fs_status fs_download_particles(fs_sim* sim, fs_particle* dst, size_t n);
+fs_status fs_upload_particles(fs_sim* sim, const fs_particle* src, size_t n);
+fs_status fs_download_start_indices(fs_sim* sim, uint32_t* dst, size_t n);
+fs_status fs_upload_start_indices(fs_sim* sim, const uint32_t* src, size_t n);
+
+/* ------------------------------------------------- host-side mirrors (pure) */
+/* Initial lattice, src/simulation.rs:147-163, f32 arithmetic as written. */
+fs_status fs_reference_lattice(const fs_settings* settings, fs_vec2 offset, fs_particle* dst, size_t n);
+/* Sort schedule, src/simulation.rs:323-347.  Returns the number of steps
+ * S(S+1)/2; fills up to `cap` entries when dst != NULL. */
+size_t fs_sort_schedule(uint32_t particle_count, fs_sort_step* dst, size_t cap);
+/* Uniform construction, src/simulation.rs:470-497. */
+fs_status fs_build_uniform(const fs_settings* settings, const fs_tick_settings* tick,
+                           uint32_t tick_count, fs_uniform* out);
+
+/* -------------------------------------------------------------- profiling */
+/* Per-pass device time measured with hipEvents on the simulation's stream. */
+enum { FS_PASS_PREDICT_KEY = 0, FS_PASS_SORT = 1, FS_PASS_REORDER = 2, FS_PASS_DENSITY = 3,
+       FS_PASS_FORCE = 4, FS_PASS_COUNT = 5 };
+fs_status fs_profile_enable(fs_sim* sim, int enable);
+/* Accumulated milliseconds per pass since the last reset and number of steps. */
+fs_status fs_profile_read(fs_sim* sim, double ms[FS_PASS_COUNT], uint64_t* steps, int reset);
+/* Time `steps` consecutive fs_step calls with one hipEvent pair on the stream. */
+fs_status fs_timed_steps(fs_sim* sim, const fs_tick_settings* tick, uint32_t steps, double* ms_total);
+
+/* ------------------------------------------------------- ResizableBuffer */
+/* ResizableBuffer<T>::new (src/buffer.rs:27-43). */
+fs_status fs_buffer_create(int device, size_t elem_size, size_t len, const char* name, fs_buffer** out);
+/* ::resize (src/buffer.rs:46-67): grow-only, copies old contents, clamps to the
+ * device maximum with a warning.  *resized = 0 when new_cap < len. */
+fs_status fs_buffer_resize(fs_buffer* buf, size_t new_cap, int* resized);
+/* ::write (src/buffer.rs:70-87): data longer than the buffer is trimmed (and
+ * logged); offset-aware superset of the reference check. */
+fs_status fs_buffer_write(fs_buffer* buf, size_t offset, const void* data, size_t count);
+fs_status fs_buffer_read(fs_buffer* buf, size_t offset, void* dst, size_t count);
+size_t fs_buffer_len(const fs_buffer* buf);      /* SSBO::len (src/buffer.rs:170-172) */
+void* fs_buffer_device_ptr(const fs_buffer* buf); /* bind_group() equivalent (src/buffer.rs:162-164) */
+void fs_buffer_destroy(fs_buffer* buf);
+
+/* ----------------------------------------------------------------- errors */
+const char* fs_last_error(void);  /* thread-local, never NULL */
+int fs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDSIM_H */

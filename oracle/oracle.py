@@ -1,0 +1,156 @@
+"""ctypes binding of the CPU oracle (oracle/sph_oracle.cpp).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "libsph_oracle.so")
+
+PARTICLE_DTYPE = np.dtype([("position", "<f4", (2,)), ("predicted_position", "<f4", (2,)),
+                           ("velocity", "<f4", (2,)), ("density", "<f4"), ("grid", "<u4")])
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in ("sph_oracle.cpp", "sph_oracle3d.cpp", "Makefile")]
+    srcs.append(os.path.join(HERE, "..", "include", "fluidsim.h"))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        P = C.c_void_p
+        L.orc_create.restype = P
+        L.orc_create.argtypes = [P, C.c_float, C.c_float, C.c_int]
+        L.orc_destroy.argtypes = [P]
+        for name in ("orc_predict", "orc_spatial_lookup", "orc_sort", "orc_cell_starts", "orc_move"):
+            getattr(L, name).argtypes = [P]
+            getattr(L, name).restype = None
+        L.orc_begin_tick.argtypes = [P, P]
+        L.orc_density.argtypes = [P, C.c_int]
+        L.orc_step.argtypes = [P, P]
+        L.orc_tick.restype = C.c_uint32
+        L.orc_tick.argtypes = [P]
+        L.orc_count.restype = C.c_uint32
+        L.orc_count.argtypes = [P]
+        L.orc_grid.argtypes = [P, P, P]
+        L.orc_particles.restype = P
+        L.orc_particles.argtypes = [P]
+        L.orc_start_indices.restype = P
+        L.orc_start_indices.argtypes = [P]
+        L.orc_start_indices_len.restype = C.c_size_t
+        L.orc_start_indices_len.argtypes = [P]
+        L.orc_texture.restype = P
+        L.orc_texture.argtypes = [P]
+        L.orc_uniform.argtypes = [P, P]
+        L.orc_poly6_norm.restype = C.c_float
+        L.orc_poly6_norm.argtypes = [P]
+        L.orc_lattice.argtypes = [P, C.c_float, C.c_float, P, C.c_size_t]
+        L.orc_sort_schedule.restype = C.c_size_t
+        L.orc_sort_schedule.argtypes = [C.c_uint32, P, C.c_size_t]
+        L.orc_build_uniform.argtypes = [P, P, C.c_uint32, P]
+        L.orc_grid_dims.argtypes = [P, P, P]
+        L.orc_bitonic_keys.argtypes = [P, P, C.c_uint32]
+        L.orc_poly6_value.restype = C.c_float
+        L.orc_poly6_value.argtypes = [C.c_float, C.c_float]
+        _lib = L
+    return _lib
+
+
+class OracleSim:
+    """CPU oracle simulation; `settings`/`tick` are the ctypes structs of the product ABI
+    (same layout as include/fluidsim.h)."""
+
+    def __init__(self, settings, initial_offset=(0.0, 0.0), ref_quirks=True):
+        self.L = lib()
+        self.settings = settings
+        self.h = self.L.orc_create(C.addressof(settings), float(initial_offset[0]), float(initial_offset[1]),
+                                   1 if ref_quirks else 0)
+        if not self.h:
+            raise ValueError("oracle: invalid settings (particle_count <= 1)")
+        self.n = int(self.L.orc_count(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, tick):
+        self.L.orc_step(self.h, C.addressof(tick))
+
+    # individual passes (reference dispatch order, src/simulation.rs:512-537)
+    def begin_tick(self, tick): self.L.orc_begin_tick(self.h, C.addressof(tick))
+    def predict(self): self.L.orc_predict(self.h)
+    def spatial_lookup(self): self.L.orc_spatial_lookup(self.h)
+    def sort(self): self.L.orc_sort(self.h)
+    def cell_starts(self): self.L.orc_cell_starts(self.h)
+    def density(self, reach=1): self.L.orc_density(self.h, int(reach))
+    def move(self): self.L.orc_move(self.h)
+
+    @property
+    def tick_count(self):
+        return int(self.L.orc_tick(self.h))
+
+    @property
+    def grid_dims(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        self.L.orc_grid(self.h, C.addressof(w), C.addressof(h))
+        return int(w.value), int(h.value)
+
+    def particles_view(self):
+        """Writable numpy view of the oracle's particle array (no copy)."""
+        ptr = self.L.orc_particles(self.h)
+        buf = (C.c_char * (self.n * 32)).from_address(ptr)
+        return np.frombuffer(buf, dtype=PARTICLE_DTYPE)
+
+    def particles(self):
+        return self.particles_view().copy()
+
+    def set_particles(self, arr):
+        self.particles_view()[:] = np.ascontiguousarray(arr, dtype=PARTICLE_DTYPE)
+
+    def start_indices_view(self):
+        ptr = self.L.orc_start_indices(self.h)
+        n = int(self.L.orc_start_indices_len(self.h))
+        buf = (C.c_char * (n * 4)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint32)
+
+    def start_indices(self):
+        return self.start_indices_view().copy()
+
+    def texture_view(self):
+        ptr = self.L.orc_texture(self.h)
+        n = int(self.settings.texture_size.x) * int(self.settings.texture_size.y)
+        buf = (C.c_char * (n * 8)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.float32).reshape(int(self.settings.texture_size.y),
+                                                            int(self.settings.texture_size.x), 2)
+
+    def uniform_bytes(self):
+        out = (C.c_char * 120)()
+        self.L.orc_uniform(self.h, C.addressof(out))
+        return bytes(out)
+
+
+def bitonic_keys(keys):
+    """Run the reference network on bare u32 keys; returns (sorted_keys, perm)."""
+    k = np.ascontiguousarray(keys, dtype=np.uint32).copy()
+    perm = np.empty_like(k)
+    lib().orc_bitonic_keys(k.ctypes.data, perm.ctypes.data, k.shape[0])
+    return k, perm
