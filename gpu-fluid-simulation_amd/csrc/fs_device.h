@@ -43,6 +43,11 @@ __device__ __forceinline__ uint32_t f32_to_u32_sat(float x) {
     return (uint32_t)x;
 }
 
+// Correctly rounded f32 sqrt.  NOT __fsqrt_rn: on ROCm 7.2 that is __ocml_native_sqrt_f32
+// (bare v_sqrt_f32, ~1 ulp).  sqrtf lowers to the IEEE sequence under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt.
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+
 __device__ __forceinline__ float sign_f32(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
 // compute.wgsl:16-26

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
             const float ox = q.x - me.x, oyv = q.y - me.y;
             const float r2 = ox * ox + oyv * oyv;
             if (r2 > P.sqr_radius) continue;                            // :202,278
-            const float dst = __fsqrt_rn(r2);
+            const float dst = fsd::sqrt_rn(r2);
             const float nrho = rho[k];
             const float2 nv = vel_s[k];
             // pressure (compute.wgsl:209-223)
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
             if (dst == 0.0f) {
                 const float rx = rand_f32(&seed);
                 const float ry = rand_f32(&seed);
-                const float len = __fsqrt_rn(rx * rx + ry * ry);
+                const float len = fsd::sqrt_rn(rx * rx + ry * ry);
                 dx = __fdiv_rn(rx, len);
                 dy = __fdiv_rn(ry, len);
             } else {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
     v.y += P.gy * P.dt;
     if (P.mouse_state != 0) {
         const float dx = P.mouse_x - me.x, dy = P.mouse_y - me.y;
-        const float dist = __fsqrt_rn(dx * dx + dy * dy);
+        const float dist = fsd::sqrt_rn(dx * dx + dy * dy);
         if (dist <= P.mouse_radius) {
             const float dirx = __fdiv_rn(__fdiv_rn(dx, dist), dist);
             const float diry = __fdiv_rn(__fdiv_rn(dy, dist), dist);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
         }
     }
     if (!(v.x == v.x && v.y == v.y)) { v.x = 0.0f; v.y = 0.0f; }
-    const float speed = __fsqrt_rn(v.x * v.x + v.y * v.y);
+    const float speed = fsd::sqrt_rn(v.x * v.x + v.y * v.y);
     if (speed > 500.0f) {
         v.x = __fdiv_rn(v.x, speed) * 500.0f;
         v.y = __fdiv_rn(v.y, speed) * 500.0f;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
         const float p2wx = __fdiv_rn(P.bounds_x * 2.0f, P.tex_w);
         const float p2wy = __fdiv_rn(P.bounds_y * 2.0f, P.tex_h);
         const float fwx = force.x * p2wx, fwy = force.y * p2wy;
-        const float len = __fsqrt_rn(force.x * force.x + force.y * force.y);
+        const float len = fsd::sqrt_rn(force.x * force.x + force.y * force.y);
         const float nx = __fdiv_rn(force.x, len), ny = __fdiv_rn(force.y, len);
         p.x += fwx;
         p.y += fwy;
