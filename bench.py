@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: M particle-steps/s on the 16M-particle 2D dam break
+(BASELINE.json `metric`, configs[2]; SURVEY.md §8d scene), one process per GPU.
+
+A "step" is one pass of the hot path (predict -> key -> bitonic sort -> cell starts ->
+density -> force+integrate) over all particles.  State is resident in HBM before the
+timed region; timing uses HIP events on the simulation's own stream (C ABI
+fs_timed_steps / fs_profile_*), bracketed by barrier + device sync, MAX over ranks.
+
+Prints ONE JSON line on rank 0 (contract fields + `roofline` + `cpu_baseline`).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# SURVEY.md §8d — algorithmic (compulsory SoA) bytes per particle-step, by pass.
+ALG_BYTES = {"predict_key": 28, "sort": 12, "reorder": 48 + 4, "density": 16, "force": 48}
+ALG_TOTAL = 156                      # 28 + 60 + 4 + 16 + 48
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0
+
+WORKLOADS = {
+    "dam_break_2d_16M": 1 << 24,
+    "dam_break_2d_1M": 1 << 20,
+    "dam_break_2d_4096": 4096,
+    "dam_break_2d_64M": 1 << 26,
+}
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (scalar C++ port of the reference step) timed on this host, 1 thread,
+    on a bounded sample of the same scene: 1M-particle dam break, as many steps as fit."""
+    import gpu_fluid_simulation_amd as g
+    from oracle import oracle as O
+    n = 1 << 20
+    st, off, tick = g.dam_break_2d(n)
+    sim = O.OracleSim(st, off)
+    sim.step(tick)                      # warm-up (page faults, first sort of the lattice)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        sim.step(tick)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or steps >= 64:
+            break
+    return {"value": round(n * steps / el / 1e6, 4), "unit": "M particle-steps/s", "cores": 1, "kind": "port",
+            "sample": f"dam_break_2d 1M particles, {steps} steps after 1 warm-up, oracle/sph_oracle.cpp scalar, "
+                      f"{el:.1f} s on {os.cpu_count()} host cores (1 used)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="dam_break_2d_16M", choices=sorted(WORKLOADS))
+    ap.add_argument("--sort", default="bitonic", choices=["bitonic", "counting"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-traffic", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if world > 1:
+        # torch first: its bundled HIP runtime has the same SONAME as /opt/rocm's, so the engine
+        # library binds to the one already loaded (one runtime per process).
+        import torch  # noqa: F401
+    import __graft_entry__ as ge
+    ge.build()
+    import gpu_fluid_simulation_amd as g
+
+    if world > 1:
+        from gpu_fluid_simulation_amd import multi
+        return multi.bench_main(args, rank, local_rank, world)
+
+    n = WORKLOADS[args.workload]
+    st, off, tick = g.dam_break_2d(n)
+    sort_mode = g.FS_SORT_BITONIC if args.sort == "bitonic" else g.FS_SORT_COUNTING
+    sim = g.FluidSimulation(st, device=local_rank, initial_offset=off, sort_mode=sort_mode)
+
+    for _ in range(args.warmup):
+        sim.tick(tick)
+    sim.sync()                                      # device idle: all work lives on the sim's stream
+    sim.profile(True)
+    sim.profile_read(reset=True)
+    t_wall = time.perf_counter()
+    ms = sim.timed_steps(tick, args.steps)          # EXACTLY K steps, HIP events on the sim stream
+    sim.sync()
+    t_wall = (time.perf_counter() - t_wall) * 1e3
+    passes, psteps = sim.profile_read(reset=True)
+    assert psteps == args.steps
+    sim.profile(False)
+
+    ms_per_step = ms / args.steps
+    value = n / (ms_per_step * 1e-3) / 1e6            # M particle-steps/s
+
+    per_pass = {}
+    for name, tot in passes.items():
+        t = tot / args.steps
+        gbs = ALG_BYTES[name] * n / (t * 1e-3) / 1e9 if t > 0 else 0.0
+        per_pass[name] = {"ms": round(t, 4), "alg_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    dom = max(per_pass, key=lambda k: per_pass[k]["ms"])
+    roofline = {
+        "bound": "hbm", "kernel": dom,
+        "achieved": per_pass[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": per_pass[dom]["frac"],
+        "traffic": args.pmc_traffic,
+        "alg_bytes_per_particle": ALG_BYTES[dom],
+        "step": {"alg_bytes_per_particle": ALG_TOTAL,
+                 "achieved": round(ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9, 1),
+                 "frac": round(ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "frac_of_measured_copy": round(ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9 / HBM_COPY_GBS, 4)},
+        "passes": per_pass,
+    }
+    out = {
+        "metric": "M particle-steps/s", "value": round(value, 2), "unit": "M particle-steps/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "particles": n, "scene": "SURVEY.md §8d dam_break_2d",
+                   "sort": args.sort, "ref_quirks": True, "parallelism": "1 GPU"},
+        "host_wall_ms_per_step": round(t_wall / args.steps, 4),
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    sim.close()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

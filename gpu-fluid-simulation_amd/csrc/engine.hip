@@ -113,9 +113,12 @@ struct fs_sim {
     uint32_t work_cap = 0;
     DevArray<fs_particle> aos;      // lazily allocated 32-byte view
 
+    // Per-pass timing: a ring of event sets recorded on the stream; drained (synchronised
+    // and accumulated) only when read or when the ring is full, never per step.
+    static const uint32_t PROF_RING = 256;
     bool profile = false;
-    hipEvent_t ev[FS_PASS_COUNT + 1] = {};
-    bool ev_ready = false;
+    std::vector<hipEvent_t> ev;     // PROF_RING * (FS_PASS_COUNT + 1)
+    uint32_t prof_pending = 0;
     double prof_ms[FS_PASS_COUNT] = {};
     uint64_t prof_steps = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -124,7 +127,8 @@ struct fs_sim {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release();
         key.release(); pairs.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
-        if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        ev.clear();
         if (t0) (void)hipEventDestroy(t0);
         if (t1) (void)hipEventDestroy(t1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -215,10 +219,26 @@ fsd::StepParams make_params(const fs_sim& s) {
 }
 
 fs_status ensure_events(fs_sim* s) {
-    if (!s->ev_ready) {
+    if (s->ev.empty()) {
+        s->ev.resize((size_t)fs_sim::PROF_RING * (FS_PASS_COUNT + 1));
         for (auto& e : s->ev) FS_HIP(hipEventCreate(&e));
-        s->ev_ready = true;
     }
+    return FS_OK;
+}
+
+fs_status drain_profile(fs_sim* s) {
+    if (s->prof_pending == 0) return FS_OK;
+    const size_t stride = FS_PASS_COUNT + 1;
+    FS_HIP(hipEventSynchronize(s->ev[(size_t)(s->prof_pending - 1) * stride + FS_PASS_COUNT]));
+    for (uint32_t j = 0; j < s->prof_pending; ++j) {
+        for (int k = 0; k < FS_PASS_COUNT; ++k) {
+            float ms = 0.0f;
+            FS_HIP(hipEventElapsedTime(&ms, s->ev[j * stride + k], s->ev[j * stride + k + 1]));
+            s->prof_ms[k] += ms;
+        }
+    }
+    s->prof_steps += s->prof_pending;
+    s->prof_pending = 0;
     return FS_OK;
 }
 
@@ -229,34 +249,34 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     const fsd::StepParams P = make_params(*s);
     hipStream_t st = s->stream;
     const bool prof = s->profile;
-    if (prof) { fs_status r = ensure_events(s); if (r != FS_OK) return r; }
+    hipEvent_t* ev = nullptr;
+    if (prof) {
+        fs_status r = ensure_events(s);
+        if (r != FS_OK) return r;
+        if (s->prof_pending == fs_sim::PROF_RING) { r = drain_profile(s); if (r != FS_OK) return r; }
+        ev = &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)];
+    }
     if (s->n == 0) return FS_OK;
 
-    if (prof) FS_HIP(hipEventRecord(s->ev[0], st));
+    if (prof) FS_HIP(hipEventRecord(ev[0], st));
     fsd::launch_predict_key(st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
-    if (prof) FS_HIP(hipEventRecord(s->ev[1], st));
+    if (prof) FS_HIP(hipEventRecord(ev[1], st));
     if (s->opts.sort_mode == FS_SORT_BITONIC) {
         fsd::launch_bitonic_sort(st, s->pairs.p, s->n);
     } else {
         return fail(FS_ERR_UNSUPPORTED, "sort_mode not built");
     }
-    if (prof) FS_HIP(hipEventRecord(s->ev[2], st));
+    if (prof) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, s->key.p, s->cs.p,
                         s->start_ref.p, s->work.p, s->counter.p, s->work_cap);
-    if (prof) FS_HIP(hipEventRecord(s->ev[3], st));
+    if (prof) FS_HIP(hipEventRecord(ev[3], st));
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p);
-    if (prof) FS_HIP(hipEventRecord(s->ev[4], st));
+    if (prof) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, s->pos.p, s->vel.p);
     if (prof) {
-        FS_HIP(hipEventRecord(s->ev[5], st));
-        FS_HIP(hipEventSynchronize(s->ev[5]));
-        for (int k = 0; k < FS_PASS_COUNT; ++k) {
-            float ms = 0.0f;
-            FS_HIP(hipEventElapsedTime(&ms, s->ev[k], s->ev[k + 1]));
-            s->prof_ms[k] += ms;
-        }
-        s->prof_steps += 1;
+        FS_HIP(hipEventRecord(ev[5], st));
+        s->prof_pending += 1;
     }
     FS_HIP(hipGetLastError());
     return FS_OK;
@@ -493,6 +513,8 @@ fs_status fs_profile_enable(fs_sim* s, int enable) {
 
 fs_status fs_profile_read(fs_sim* s, double ms[FS_PASS_COUNT], uint64_t* steps, int reset) {
     if (!s || !ms) return fail(FS_ERR_INVALID, "null argument");
+    fs_status r = drain_profile(s);
+    if (r != FS_OK) return r;
     for (int k = 0; k < FS_PASS_COUNT; ++k) ms[k] = s->prof_ms[k];
     if (steps) *steps = s->prof_steps;
     if (reset) { for (auto& m : s->prof_ms) m = 0.0; s->prof_steps = 0; }

@@ -171,6 +171,51 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
 }
 
 // ---------------------------------------------------------- force + integrate
+// Two phases per lane so the expensive IEEE divide/sqrt body runs with dense lanes:
+//   scan  — walk the three row ranges, test `k != i && !(r2 > sqr_radius)` (compute.wgsl:195,202),
+//           append passing indices to a per-lane list in LDS (entry-major: conflict-free);
+//   heavy — pressure + viscosity terms for the listed neighbours, accumulated in list order,
+//           which is the reference visiting order, so sums keep their association.
+// A full list (FORCE_CAP) is flushed wave-uniformly and scanning resumes.
+#define FORCE_CAP 32
+
+struct ForceAcc { float fpx, fpy, fvx, fvy; uint32_t seed; };
+
+__device__ __forceinline__ void force_pair(const StepParams& P, const float2 me, const float2 mv, float pressure,
+                                           const float2 q, const float2 nv, float nrho, ForceAcc& A) {
+    const float h = P.h;
+    const float ox = q.x - me.x, oyv = q.y - me.y;
+    const float r2 = ox * ox + oyv * oyv;
+    const float dst = sqrt_rn(r2);                                      // compute.wgsl:207,283
+    float dx, dy;
+    if (dst == 0.0f) {                                                  // :211-212
+        const float rx = rand_f32(&A.seed);
+        const float ry = rand_f32(&A.seed);
+        const float len = sqrt_rn(rx * rx + ry * ry);
+        dx = __fdiv_rn(rx, len);
+        dy = __fdiv_rn(ry, len);
+    } else {
+        dx = __fdiv_rn(ox, dst);
+        dy = __fdiv_rn(oyv, dst);
+    }
+    const float npress = P.pressure_k * (nrho - P.rest_density);
+    const float kern = (dst <= h) ? (-(h - dst)) * P.spiky : 0.0f;      // funcs.wgsl:101-109
+    const float shared = (pressure + npress) * 0.5f;
+    A.fpx += __fdiv_rn(dx * kern * shared, nrho);                       // compute.wgsl:223
+    A.fpy += __fdiv_rn(dy * kern * shared, nrho);
+    float kv = 0.0f;                                                    // funcs.wgsl:112-123
+    if (dst <= h) {
+        if (dst == 0.0f) {
+            kv = P.visc_k;
+        } else {
+            kv = P.visc_k * ((__fdiv_rn(-(dst * dst * dst), 2.0f * h * h * h)) + (__fdiv_rn(dst * dst, h * h)) +
+                             (__fdiv_rn(h, 2.0f * dst)) - 1.0f);
+        }
+    }
+    A.fvx += __fdiv_rn(nv.x - mv.x, nrho) * kv;                         // compute.wgsl:288
+    A.fvy += __fdiv_rn(nv.y - mv.y, nrho) * kv;
+}
+
 __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* __restrict__ pos_s,
                                                     const float2* __restrict__ vel_s,
                                                     const float2* __restrict__ pred, const float* __restrict__ rho,
@@ -178,76 +223,66 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
                                                     const uint32_t* __restrict__ start_ref,
                                                     const u64* __restrict__ pairs, const float2* __restrict__ tex,
                                                     float2* __restrict__ pos_out, float2* __restrict__ vel_out) {
-    const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
-    if (i >= P.n) return;
+    __shared__ uint32_t s_list[FORCE_CAP * FS_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * FS_BLOCK + tid;
+    const bool live = i < P.n;
+    const uint32_t ii = live ? i : P.n - 1;          // dead lanes shadow the last particle, store nothing
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
-    const float2 me = pred[i];
-    const float2 mv = vel_s[i];
-    const float mrho = rho[i];
+    const float2 me = pred[ii];
+    const float2 mv = vel_s[ii];
+    const float mrho = rho[ii];
     const float pressure = P.pressure_k * (mrho - P.rest_density);      // funcs.wgsl:152-154
-    uint32_t seed = i * 12u + P.frame_time * 69u;                      // compute.wgsl:161
+    ForceAcc A;
+    A.fpx = A.fpy = A.fvx = A.fvy = 0.0f;
+    A.seed = ii * 12u + P.frame_time * 69u;                             // compute.wgsl:161
     uint32_t cx, cy;
     xy_of_point(P, me, &cx, &cy);
-    float fpx = 0.0f, fpy = 0.0f, fvx = 0.0f, fvy = 0.0f;
-    const float h = P.h;
+    uint32_t cnt = 0;
 #pragma unroll 1
-    for (int oy = -1; oy <= 1; ++oy) {
-        uint32_t lo, hi;
-        if (!row_range(P, cs, cx, cy + (uint32_t)oy, lo_fix, &lo, &hi)) continue;
-        for (uint32_t k = lo; k < hi; ++k) {
-            if (k == i) continue;                                       // compute.wgsl:195,271
-            const float2 q = pred[k];
-            const float ox = q.x - me.x, oyv = q.y - me.y;
-            const float r2 = ox * ox + oyv * oyv;
-            if (r2 > P.sqr_radius) continue;                            // :202,278
-            const float dst = fsd::sqrt_rn(r2);
-            const float nrho = rho[k];
-            const float2 nv = vel_s[k];
-            // pressure (compute.wgsl:209-223)
-            float dx, dy;
-            if (dst == 0.0f) {
-                const float rx = rand_f32(&seed);
-                const float ry = rand_f32(&seed);
-                const float len = fsd::sqrt_rn(rx * rx + ry * ry);
-                dx = __fdiv_rn(rx, len);
-                dy = __fdiv_rn(ry, len);
-            } else {
-                dx = __fdiv_rn(ox, dst);
-                dy = __fdiv_rn(oyv, dst);
+    for (int oy = -1; oy <= 2; ++oy) {
+        uint32_t lo = 0, hi = 0;
+        if (live && oy <= 1) (void)row_range(P, cs, cx, cy + (uint32_t)oy, lo_fix, &lo, &hi);
+        if (oy > 1) hi = lo;                                            // 4th trip only flushes
+        uint32_t k = lo;
+        for (;;) {
+            // scan until this lane's row is exhausted or its list is full
+            while (k < hi && cnt < FORCE_CAP) {
+                const float2 q = pred[k];
+                const float ox = q.x - me.x, oyv = q.y - me.y;
+                const float r2 = ox * ox + oyv * oyv;
+                if (k != ii && !(r2 > P.sqr_radius)) { s_list[cnt * FS_BLOCK + tid] = k; ++cnt; }
+                ++k;
             }
-            const float npress = P.pressure_k * (nrho - P.rest_density);
-            const float kern = (dst <= h) ? (-(h - dst)) * P.spiky : 0.0f;   // funcs.wgsl:101-109
-            const float shared = (pressure + npress) * 0.5f;
-            fpx += __fdiv_rn(dx * kern * shared, nrho);
-            fpy += __fdiv_rn(dy * kern * shared, nrho);
-            // viscosity (compute.wgsl:283-288, funcs.wgsl:112-123)
-            float kv = 0.0f;
-            if (dst <= h) {
-                if (dst == 0.0f) {
-                    kv = P.visc_k;
-                } else {
-                    kv = P.visc_k * ((__fdiv_rn(-(dst * dst * dst), 2.0f * h * h * h)) + (__fdiv_rn(dst * dst, h * h)) +
-                                     (__fdiv_rn(h, 2.0f * dst)) - 1.0f);
+            const bool full = cnt == FORCE_CAP && k < hi;
+            const bool flush = __any(full) || oy > 1;
+            if (flush) {
+                for (uint32_t e = 0; __any(e < cnt); ++e) {
+                    if (e < cnt) {
+                        const uint32_t j = s_list[e * FS_BLOCK + tid];
+                        force_pair(P, me, mv, pressure, pred[j], vel_s[j], rho[j], A);
+                    }
                 }
+                cnt = 0;
             }
-            fvx += __fdiv_rn(nv.x - mv.x, nrho) * kv;
-            fvy += __fdiv_rn(nv.y - mv.y, nrho) * kv;
+            if (!__any(k < hi)) break;
         }
     }
-    fvx = fvx * P.visc_coeff;                                           // compute.wgsl:298
-    fvy = fvy * P.visc_coeff;
+    if (!live) return;
+    const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
+    const float fvy = A.fvy * P.visc_coeff;
 
     // integrate (compute.wgsl:93-153)
     float2 v = mv;
     float2 p = pos_s[i];
-    const float ax = fpx + fvx, ay = fpy + fvy;
+    const float ax = A.fpx + fvx, ay = A.fpy + fvy;
     v.x += __fdiv_rn(ax, mrho) * P.dt;
     v.y += __fdiv_rn(ay, mrho) * P.dt;
     v.x += P.gx * P.dt;
     v.y += P.gy * P.dt;
     if (P.mouse_state != 0) {
         const float dx = P.mouse_x - me.x, dy = P.mouse_y - me.y;
-        const float dist = fsd::sqrt_rn(dx * dx + dy * dy);
+        const float dist = sqrt_rn(dx * dx + dy * dy);
         if (dist <= P.mouse_radius) {
             const float dirx = __fdiv_rn(__fdiv_rn(dx, dist), dist);
             const float diry = __fdiv_rn(__fdiv_rn(dy, dist), dist);
@@ -257,7 +292,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
         }
     }
     if (!(v.x == v.x && v.y == v.y)) { v.x = 0.0f; v.y = 0.0f; }
-    const float speed = fsd::sqrt_rn(v.x * v.x + v.y * v.y);
+    const float speed = sqrt_rn(v.x * v.x + v.y * v.y);
     if (speed > 500.0f) {
         v.x = __fdiv_rn(v.x, speed) * 500.0f;
         v.y = __fdiv_rn(v.y, speed) * 500.0f;
@@ -276,7 +311,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
         const float p2wx = __fdiv_rn(P.bounds_x * 2.0f, P.tex_w);
         const float p2wy = __fdiv_rn(P.bounds_y * 2.0f, P.tex_h);
         const float fwx = force.x * p2wx, fwy = force.y * p2wy;
-        const float len = fsd::sqrt_rn(force.x * force.x + force.y * force.y);
+        const float len = sqrt_rn(force.x * force.x + force.y * force.y);
         const float nx = __fdiv_rn(force.x, len), ny = __fdiv_rn(force.y, len);
         p.x += fwx;
         p.y += fwy;
