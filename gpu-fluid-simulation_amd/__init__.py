@@ -23,6 +23,8 @@ from ._abi import (  # noqa: F401
     ExtensionMissing,
     Options,
     Settings,
+    SlabConfig,
+    SlabCounters,
     SortStep,
     TickSettings,
     Uniform,
@@ -196,6 +198,88 @@ class FluidSimulation:
         p, n = C.c_void_p(), C.c_size_t()
         _check(self._lib, self._lib.fs_start_indices_device(self._h, C.byref(p), C.byref(n)))
         return p.value, int(n.value)
+
+
+class SlabSimulation:
+    """One rank of the multi-GPU slab decomposition (include/fluidsim.h fs_slab_*).
+
+    Owns the global cell columns [own_lo, own_hi).  A step is pack() -> exchange the two
+    messages with the slab neighbours -> step(); see multi.py for the driver.
+    """
+
+    def __init__(self, settings, own_lo, own_hi, has_left, has_right, capacity, recv_capacity, max_cols, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.settings = settings
+        self.cfg = SlabConfig(int(own_lo), int(own_hi), int(bool(has_left)), int(bool(has_right)), int(capacity),
+                              int(recv_capacity), int(max_cols), 0)
+        _check(self._lib, self._lib.fs_slab_create(C.byref(settings), int(device), C.byref(self.cfg), C.byref(self._h)))
+        self.capacity = int(capacity)
+        self.message_bytes = int(self._lib.fs_slab_message_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.fs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_owned(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=PARTICLE_DTYPE)
+        _check(self._lib, self._lib.fs_slab_upload_owned(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0]))
+
+    def set_window(self, own_lo, own_hi):
+        _check(self._lib, self._lib.fs_slab_set_window(self._h, int(own_lo), int(own_hi)))
+        self.cfg.own_lo, self.cfg.own_hi = int(own_lo), int(own_hi)
+
+    def pack(self, tick_settings, send_left_ptr, send_right_ptr):
+        _check(self._lib, self._lib.fs_slab_pack(self._h, C.byref(tick_settings), send_left_ptr, send_right_ptr))
+
+    def step(self, recv_left_ptr, recv_right_ptr):
+        _check(self._lib, self._lib.fs_slab_step(self._h, recv_left_ptr, recv_right_ptr))
+
+    def sync(self):
+        _check(self._lib, self._lib.fs_sync(self._h))
+
+    @property
+    def stream_ptr(self):
+        return self._lib.fs_stream(self._h)
+
+    @property
+    def tick_count(self):
+        return int(self._lib.fs_tick_count(self._h))
+
+    def counters(self):
+        c = SlabCounters()
+        _check(self._lib, self._lib.fs_slab_counters_read(self._h, C.byref(c)))
+        return {"n_live": c.n_live, "lost": c.lost, "overflow": c.overflow, "far_halo": c.far_halo}
+
+    def download(self):
+        """(records with GLOBAL cell keys, owned mask) of the live slots."""
+        out = np.empty(self.capacity, dtype=PARTICLE_DTYPE)
+        owned = np.zeros(self.capacity, dtype=np.uint8)
+        n = C.c_uint32()
+        _check(self._lib, self._lib.fs_slab_download(self._h, out.ctypes.data_as(C.c_void_p),
+                                                     owned.ctypes.data_as(C.c_void_p), self.capacity, C.byref(n)))
+        return out[: n.value], owned[: n.value].astype(bool)
+
+    def column_histogram(self, grid_w_global):
+        h = np.zeros(int(grid_w_global), dtype=np.uint32)
+        _check(self._lib, self._lib.fs_slab_column_histogram(self._h, h.ctypes.data_as(C.c_void_p), h.shape[0]))
+        return h
+
+    def profile(self, enable=True):
+        _check(self._lib, self._lib.fs_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * len(PASS_NAMES))()
+        steps = C.c_uint64()
+        _check(self._lib, self._lib.fs_profile_read(self._h, ms, C.byref(steps), 1 if reset else 0))
+        return dict(zip(PASS_NAMES, [float(x) for x in ms])), int(steps.value)
 
 
 class ResizableBuffer:

@@ -101,6 +101,19 @@ class Options(C.Structure):
     ]
 
 
+class SlabConfig(C.Structure):
+    _fields_ = [
+        ("own_lo", C.c_uint32), ("own_hi", C.c_uint32),
+        ("has_left", C.c_uint32), ("has_right", C.c_uint32),
+        ("capacity", C.c_uint32), ("recv_capacity", C.c_uint32),
+        ("max_cols", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class SlabCounters(C.Structure):
+    _fields_ = [("n_live", C.c_uint32), ("lost", C.c_uint32), ("overflow", C.c_uint32), ("far_halo", C.c_uint32)]
+
+
 # 32-byte AoS particle record as a numpy structured dtype (offsets 0/8/16/24/28).
 PARTICLE_DTYPE = np.dtype(
     [
@@ -155,6 +168,15 @@ PROTOTYPES = {
     "fs_profile_enable": (C.c_int, [_P, C.c_int]),
     "fs_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "fs_timed_steps": (C.c_int, [_P, C.POINTER(TickSettings), C.c_uint32, C.POINTER(C.c_double)]),
+    "fs_slab_create": (C.c_int, [C.POINTER(Settings), C.c_int, C.POINTER(SlabConfig), C.POINTER(_P)]),
+    "fs_slab_upload_owned": (C.c_int, [_P, _P, C.c_size_t]),
+    "fs_slab_set_window": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "fs_slab_message_bytes": (C.c_size_t, [_P]),
+    "fs_slab_pack": (C.c_int, [_P, C.POINTER(TickSettings), _P, _P]),
+    "fs_slab_step": (C.c_int, [_P, _P, _P]),
+    "fs_slab_counters_read": (C.c_int, [_P, C.POINTER(SlabCounters)]),
+    "fs_slab_download": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "fs_slab_column_histogram": (C.c_int, [_P, _P, C.c_size_t]),
     "fs_buffer_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_char_p, C.POINTER(_P)]),
     "fs_buffer_resize": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_int)]),
     "fs_buffer_write": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),

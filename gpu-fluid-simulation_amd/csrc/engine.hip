@@ -113,6 +113,16 @@ struct fs_sim {
     uint32_t work_cap = 0;
     DevArray<fs_particle> aos;      // lazily allocated 32-byte view
 
+    // slab (multi-GPU) mode
+    bool slab = false;
+    fs_slab_config slab_cfg{};
+    uint32_t slab_main = 0;         // capacity - 2 * recv_capacity
+    DevArray<unsigned char> owned, flags;
+    DevArray<uint2> blockcnt, blockoff;
+    DevArray<uint32_t> slab_counters;   // [0] n_live, [2] lost, [3] overflow, [4] far_halo
+    DevArray<uint32_t> hist;
+    bool slab_packed = false;
+
     // Per-pass timing: a ring of event sets recorded on the stream; drained (synchronised
     // and accumulated) only when read or when the ring is full, never per step.
     static const uint32_t PROF_RING = 256;
@@ -127,6 +137,8 @@ struct fs_sim {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release();
         key.release(); pairs.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
+        owned.release(); flags.release(); blockcnt.release(); blockoff.release(); slab_counters.release();
+        hist.release();
         for (auto& e : ev) (void)hipEventDestroy(e);
         ev.clear();
         if (t0) (void)hipEventDestroy(t0);
@@ -215,6 +227,20 @@ fsd::StepParams make_params(const fs_sim& s) {
     P.tex_w_u = s.settings.texture_size.x;   // u32(u.texture_size.x), compute.wgsl:129
     P.tex_len = (uint32_t)s.tex.n;
     P.ref_quirks = s.opts.ref_quirks;
+    P.col_origin = 0;
+    P.own_lo = 0; P.own_hi = s.grid_w;
+    P.grid_w_global = s.grid_w;
+    P.n_live = nullptr;
+    if (s.slab) {
+        // local window: 1 padding + 2 ghost columns each side of [own_lo, own_hi)
+        P.grid_w = s.slab_cfg.own_hi - s.slab_cfg.own_lo + 6u;
+        P.ncell = P.grid_w * s.grid_h;
+        P.col_origin = (int32_t)s.slab_cfg.own_lo - 3;
+        P.own_lo = s.slab_cfg.own_lo; P.own_hi = s.slab_cfg.own_hi;
+        P.n = s.capacity;
+        P.n_live = s.slab_counters.p;
+        P.ref_quirks = 0;   // the global stale-start quirk cannot exist per rank (§8e)
+    }
     return P;
 }
 
@@ -383,6 +409,7 @@ void fs_destroy(fs_sim* s) {
 
 fs_status fs_step(fs_sim* s, const fs_tick_settings* t) {
     if (!s || !t) return fail(FS_ERR_INVALID, "null argument");
+    if (s->slab) return fail(FS_ERR_INVALID, "slab handle: use fs_slab_pack / fs_slab_step");
     FS_HIP(hipSetDevice(s->device));
     return enqueue_step(s, t);
 }
@@ -534,6 +561,208 @@ fs_status fs_timed_steps(fs_sim* s, const fs_tick_settings* t, uint32_t steps, d
     float ms = 0.0f;
     FS_HIP(hipEventElapsedTime(&ms, s->t0, s->t1));
     *ms_total = ms;
+    return FS_OK;
+}
+
+/* ------------------------------------------------------------ slab mode */
+fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_config* cfg, fs_sim** out) {
+    if (!settings || !cfg || !out) return fail(FS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::string why;
+    if (!settings_valid(*settings, &why)) return fail(FS_ERR_INVALID, why);
+    uint32_t gw, gh;
+    grid_dims(*settings, &gw, &gh);
+    if (cfg->own_lo >= cfg->own_hi || cfg->own_hi > gw) return fail(FS_ERR_INVALID, "bad owned window");
+    if (cfg->own_hi - cfg->own_lo < 4) return fail(FS_ERR_INVALID, "slab narrower than 4 columns");
+    if (cfg->max_cols < cfg->own_hi - cfg->own_lo) return fail(FS_ERR_INVALID, "max_cols < window");
+    if (cfg->capacity <= 2 * cfg->recv_capacity || cfg->recv_capacity == 0)
+        return fail(FS_ERR_INVALID, "capacity must exceed 2*recv_capacity");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FS_ERR_DEVICE, "no HIP device: the engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(FS_ERR_INVALID, "device ordinal out of range");
+    FS_HIP(hipSetDevice(device));
+
+    fs_sim* s = new (std::nothrow) fs_sim();
+    if (!s) return fail(FS_ERR_OOM, "host allocation failed");
+    s->settings = *settings;
+    fs_options_default(&s->opts);
+    s->opts.device = device;
+    s->opts.ref_quirks = 0;
+    s->device = device;
+    s->slab = true;
+    s->slab_cfg = *cfg;
+    s->capacity = cfg->capacity;
+    s->n = 0;
+    s->slab_main = cfg->capacity - 2 * cfg->recv_capacity;
+    s->grid_w = gw; s->grid_h = gh;
+    const uint32_t wmax = cfg->max_cols + 6u;
+    s->ncell = wmax * gh;                       // allocation size of the local grid
+    s->work_cap = s->ncell / 16u + 1024u;
+    auto bail = [&](fs_status st) { s->release(); delete s; return st; };
+#define FS_TRY(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e__ = (expr);                                                                              \
+        if (e__ != hipSuccess)                                                                                \
+            return bail(fail(e__ == hipErrorOutOfMemory ? FS_ERR_OOM : FS_ERR_DEVICE,                         \
+                             std::string(#expr) + ": " + hipGetErrorString(e__)));                            \
+    } while (0)
+    FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const size_t cap = s->capacity;
+    FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
+    FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->owned.alloc(cap)); FS_TRY(s->flags.alloc(cap));
+    const size_t nblocks = (cap + 255) / 256;
+    FS_TRY(s->blockcnt.alloc(nblocks)); FS_TRY(s->blockoff.alloc(nblocks));
+    FS_TRY(s->slab_counters.alloc(8));
+    FS_TRY(s->hist.alloc(gw));
+    FS_TRY(s->cs.alloc((size_t)s->ncell + 1)); FS_TRY(s->start_ref.alloc(s->ncell));
+    FS_TRY(s->tex.alloc((size_t)settings->texture_size.x * settings->texture_size.y));
+    FS_TRY(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
+    FS_TRY(s->counter.alloc(4));
+    FS_TRY(s->aos.alloc(cap));
+    FS_TRY(hipEventCreate(&s->t0)); FS_TRY(hipEventCreate(&s->t1));
+    FS_TRY(hipMemsetAsync(s->start_ref.p, 0, s->start_ref.n * sizeof(uint32_t), s->stream));
+    FS_TRY(hipMemsetAsync(s->cs.p, 0, s->cs.n * sizeof(uint32_t), s->stream));
+    if (s->tex.n) FS_TRY(hipMemsetAsync(s->tex.p, 0, s->tex.n * sizeof(float2), s->stream));
+    FS_TRY(hipMemsetAsync(s->counter.p, 0, 4 * sizeof(uint32_t), s->stream));
+    FS_TRY(hipMemsetAsync(s->slab_counters.p, 0, 8 * sizeof(uint32_t), s->stream));
+    FS_TRY(hipMemsetAsync(s->owned.p, 0, cap, s->stream));
+    FS_TRY(hipMemsetAsync(s->flags.p, 0, cap, s->stream));
+    FS_TRY(hipMemsetAsync(s->rho.p, 0, cap * sizeof(float), s->stream));
+    FS_TRY(hipMemsetAsync(s->pos.p, 0, cap * sizeof(float2), s->stream));
+    FS_TRY(hipMemsetAsync(s->vel.p, 0, cap * sizeof(float2), s->stream));
+    FS_TRY(hipMemsetAsync(s->pred.p, 0, cap * sizeof(float2), s->stream));
+    FS_TRY(hipMemsetAsync(s->key.p, 0xFF, cap * sizeof(uint32_t), s->stream));
+    FS_TRY(hipStreamSynchronize(s->stream));
+#undef FS_TRY
+    fs_tick_settings t0;
+    std::memset(&t0, 0, sizeof t0);
+    host_uniform(*settings, t0, 0, &s->uniform);
+    *out = s;
+    return FS_OK;
+}
+
+fs_status fs_slab_upload_owned(fs_sim* s, const fs_particle* src, size_t n) {
+    if (!s || !s->slab || (!src && n)) return fail(FS_ERR_INVALID, "bad argument");
+    if (n > s->slab_main) return fail(FS_ERR_INVALID, "more owned particles than main slots");
+    FS_HIP(hipSetDevice(s->device));
+    if (n) FS_HIP(hipMemcpyAsync(s->aos.p, src, n * sizeof(fs_particle), hipMemcpyHostToDevice, s->stream));
+    const fsd::StepParams P = make_params(*s);
+    fsd::launch_slab_import(s->stream, P, (uint32_t)n, s->capacity, s->aos.p, s->pos.p, s->pred.p, s->vel.p, s->rho.p,
+                            s->key.p, s->owned.p);
+    const uint32_t nl = (uint32_t)n;
+    FS_HIP(hipMemcpyAsync(s->slab_counters.p, &nl, sizeof nl, hipMemcpyHostToDevice, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+fs_status fs_slab_set_window(fs_sim* s, uint32_t own_lo, uint32_t own_hi) {
+    if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
+    if (own_lo >= own_hi || own_hi > s->grid_w || own_hi - own_lo < 4 || own_hi - own_lo > s->slab_cfg.max_cols)
+        return fail(FS_ERR_INVALID, "bad owned window");
+    if (s->slab_packed) return fail(FS_ERR_INVALID, "window change between pack and step");
+    s->slab_cfg.own_lo = own_lo;
+    s->slab_cfg.own_hi = own_hi;
+    return FS_OK;
+}
+
+size_t fs_slab_message_bytes(const fs_sim* s) {
+    return (s && s->slab) ? fsd::slab_message_bytes(s->slab_cfg.recv_capacity) : 0;
+}
+
+fs_status fs_slab_pack(fs_sim* s, const fs_tick_settings* t, void* send_left, void* send_right) {
+    if (!s || !s->slab || !t) return fail(FS_ERR_INVALID, "bad argument");
+    if (s->slab_packed) return fail(FS_ERR_INVALID, "fs_slab_pack called twice without fs_slab_step");
+    if ((s->slab_cfg.has_left && !send_left) || (s->slab_cfg.has_right && !send_right))
+        return fail(FS_ERR_INVALID, "missing outgoing message buffer");
+    FS_HIP(hipSetDevice(s->device));
+    s->tick += 1;
+    host_uniform(s->settings, *t, s->tick, &s->uniform);
+    const fsd::StepParams P = make_params(*s);
+    if (s->profile) {
+        fs_status r = ensure_events(s);
+        if (r != FS_OK) return r;
+        if (s->prof_pending == fs_sim::PROF_RING) { r = drain_profile(s); if (r != FS_OK) return r; }
+        FS_HIP(hipEventRecord(s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)], s->stream));
+    }
+    fsd::launch_slab_pack(s->stream, P, s->slab_main, s->slab_cfg.recv_capacity, (int)s->slab_cfg.has_left,
+                          (int)s->slab_cfg.has_right, s->pos.p, s->vel.p, s->owned.p, s->pairs.p, s->flags.p,
+                          s->blockcnt.p, s->blockoff.p, s->slab_cfg.has_left ? send_left : nullptr,
+                          s->slab_cfg.has_right ? send_right : nullptr, s->slab_counters.p, s->counter.p);
+    FS_HIP(hipGetLastError());
+    s->slab_packed = true;
+    return FS_OK;
+}
+
+fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right) {
+    if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
+    if (!s->slab_packed) return fail(FS_ERR_INVALID, "fs_slab_step without fs_slab_pack");
+    if ((s->slab_cfg.has_left && !recv_left) || (s->slab_cfg.has_right && !recv_right))
+        return fail(FS_ERR_INVALID, "missing incoming message buffer");
+    FS_HIP(hipSetDevice(s->device));
+    const fsd::StepParams P = make_params(*s);
+    hipStream_t st = s->stream;
+    hipEvent_t* ev = s->profile ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
+    fsd::launch_slab_unpack(st, P, s->slab_main, s->slab_cfg.recv_capacity, s->slab_cfg.has_left ? recv_left : nullptr,
+                            s->slab_cfg.has_right ? recv_right : nullptr, s->pos.p, s->vel.p, s->pairs.p,
+                            s->slab_counters.p);
+    if (ev) FS_HIP(hipEventRecord(ev[1], st));
+    fsd::launch_bitonic_sort(st, s->pairs.p, s->capacity);
+    if (ev) FS_HIP(hipEventRecord(ev[2], st));
+    fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
+                             s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,
+                             s->slab_counters.p);
+    if (ev) FS_HIP(hipEventRecord(ev[3], st));
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p);
+    if (ev) FS_HIP(hipEventRecord(ev[4], st));
+    fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho.p, s->cs.p, s->start_ref.p, s->pairs.p,
+                      s->tex.p, s->pos.p, s->vel.p);
+    if (ev) { FS_HIP(hipEventRecord(ev[5], st)); s->prof_pending += 1; }
+    FS_HIP(hipGetLastError());
+    s->slab_packed = false;
+    return FS_OK;
+}
+
+fs_status fs_slab_counters_read(fs_sim* s, fs_slab_counters* out) {
+    if (!s || !s->slab || !out) return fail(FS_ERR_INVALID, "bad argument");
+    FS_HIP(hipSetDevice(s->device));
+    uint32_t c[8];
+    FS_HIP(hipMemcpyAsync(c, s->slab_counters.p, sizeof c, hipMemcpyDeviceToHost, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    out->n_live = c[0]; out->lost = c[2]; out->overflow = c[3]; out->far_halo = c[4];
+    return FS_OK;
+}
+
+fs_status fs_slab_download(fs_sim* s, fs_particle* dst, uint8_t* owned, size_t cap, uint32_t* n_live) {
+    if (!s || !s->slab || !dst || !owned || !n_live) return fail(FS_ERR_INVALID, "bad argument");
+    FS_HIP(hipSetDevice(s->device));
+    const fsd::StepParams P = make_params(*s);
+    uint32_t nl = 0;
+    FS_HIP(hipMemcpyAsync(&nl, s->slab_counters.p, sizeof nl, hipMemcpyDeviceToHost, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    if (nl > s->capacity) nl = s->capacity;
+    *n_live = nl;
+    const size_t n = nl < cap ? nl : cap;
+    if (n == 0) return FS_OK;
+    // before the first step the state lives in pos/vel (import); afterwards pos/vel hold the advanced state
+    fsd::launch_slab_export(s->stream, P, (uint32_t)n, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p, s->aos.p);
+    FS_HIP(hipMemcpyAsync(dst, s->aos.p, n * sizeof(fs_particle), hipMemcpyDeviceToHost, s->stream));
+    FS_HIP(hipMemcpyAsync(owned, s->owned.p, n, hipMemcpyDeviceToHost, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+fs_status fs_slab_column_histogram(fs_sim* s, uint32_t* hist, size_t grid_w_global) {
+    if (!s || !s->slab || !hist || grid_w_global < s->grid_w) return fail(FS_ERR_INVALID, "bad argument");
+    FS_HIP(hipSetDevice(s->device));
+    const fsd::StepParams P = make_params(*s);
+    FS_HIP(hipMemsetAsync(s->hist.p, 0, s->hist.n * sizeof(uint32_t), s->stream));
+    fsd::launch_slab_colhist(s->stream, P, s->cs.p, s->hist.p);
+    std::vector<uint32_t> tmp(s->grid_w);
+    FS_HIP(hipMemcpyAsync(tmp.data(), s->hist.p, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    for (uint32_t c = s->slab_cfg.own_lo; c < s->slab_cfg.own_hi; ++c) hist[c] = tmp[c];
     return FS_OK;
 }
 

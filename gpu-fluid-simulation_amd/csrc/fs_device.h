@@ -34,7 +34,14 @@ struct StepParams {
     float tex_w, tex_h;
     uint32_t tex_w_u, tex_len;
     int32_t ref_quirks;
+    // --- slab (multi-GPU) mode: the local grid is a window of global cell columns -------------
+    int32_t col_origin;        // global column of local column 0 (0 on a single GPU)
+    uint32_t own_lo, own_hi;   // owned window [own_lo, own_hi) in GLOBAL columns
+    uint32_t grid_w_global;
+    const uint32_t* n_live;    // device-side live count (slab mode); nullptr -> n
 };
+
+#define FS_DEAD_KEY 0xFFFFFFFFu   // slot holds no particle (slab mode); sorts to the end
 
 // WGSL f32 -> u32 conversion: saturating, NaN -> 0.
 __device__ __forceinline__ uint32_t f32_to_u32_sat(float x) {
@@ -73,6 +80,12 @@ __device__ __forceinline__ uint32_t cell_of_point(const StepParams& P, float2 pt
     uint32_t cx, cy;
     xy_of_point(P, pt, &cx, &cy);
     return cy * P.grid_w + cx;
+}
+
+// Local cell coordinates in slab mode (col_origin == 0 on a single GPU: identity).
+__device__ __forceinline__ void xy_local(const StepParams& P, float2 pt, uint32_t* cx, uint32_t* cy) {
+    xy_of_point(P, pt, cx, cy);
+    *cx = (uint32_t)((int32_t)*cx - P.col_origin);
 }
 
 // funcs.wgsl:129-149

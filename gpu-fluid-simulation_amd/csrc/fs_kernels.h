@@ -23,6 +23,25 @@ void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const floa
 void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, float2* pred, float2* vel, float* rho,
                        uint32_t* key);
 size_t gap_entry_size();
+void launch_fill_gaps(hipStream_t st, uint32_t* cs, const void* work, const uint32_t* counter, uint32_t work_cap);
+
+// ---- slab (multi-GPU) mode, kernels_slab.hip -------------------------------------------------
+void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, int has_left,
+                      int has_right, const float2* pos, const float2* vel, const unsigned char* owned, u64* pairs,
+                      unsigned char* flags, void* blockcnt, void* blockoff, void* msg_left, void* msg_right,
+                      uint32_t* counters, uint32_t* gap_counter);
+void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, const void* msg_left,
+                        const void* msg_right, float2* pos, float2* vel, u64* pairs, uint32_t* counters);
+void launch_slab_reorder(hipStream_t st, const StepParams& P, uint32_t cap, const u64* pairs, const float2* pos_in,
+                         const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s,
+                         unsigned char* owned, uint32_t* cs, uint32_t* start_ref, void* work, uint32_t* counter,
+                         uint32_t work_cap, uint32_t* n_live_out);
+void launch_slab_export(hipStream_t st, const StepParams& P, uint32_t cap, const float2* pos, const float2* pred,
+                        const float2* vel, const float* rho, const uint32_t* key, void* out);
+void launch_slab_import(hipStream_t st, const StepParams& P, uint32_t n, uint32_t cap, const void* in, float2* pos,
+                        float2* pred, float2* vel, float* rho, uint32_t* key, unsigned char* owned);
+void launch_slab_colhist(hipStream_t st, const StepParams& P, const uint32_t* cs, uint32_t* hist_global);
+size_t slab_message_bytes(uint32_t R);
 
 // Bitonic network of sort.wgsl:27-51 / simulation.rs:323-347 on (key<<32 | index) pairs.
 // Returns the number of kernel launches issued.

@@ -143,11 +143,12 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
                                                       const uint32_t* __restrict__ start_ref,
                                                       const u64* __restrict__ pairs, float* __restrict__ rho_out) {
     const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
-    if (i >= P.n) return;
+    const uint32_t n = P.n_live ? *P.n_live : P.n;
+    if (i >= n) return;
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
     const float2 me = pred[i];
     uint32_t cx, cy;
-    xy_of_point(P, me, &cx, &cy);
+    xy_local(P, me, &cx, &cy);
     const float h2 = P.h * P.h;     // funcs.wgsl:73
     float rho = 0.0f;
 #pragma unroll 1
@@ -226,8 +227,10 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
     __shared__ uint32_t s_list[FORCE_CAP * FS_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * FS_BLOCK + tid;
-    const bool live = i < P.n;
-    const uint32_t ii = live ? i : P.n - 1;          // dead lanes shadow the last particle, store nothing
+    const uint32_t n = P.n_live ? *P.n_live : P.n;
+    if (n == 0) return;
+    bool live = i < n;
+    const uint32_t ii = live ? i : n - 1;            // dead lanes shadow the last particle, store nothing
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
     const float2 me = pred[ii];
     const float2 mv = vel_s[ii];
@@ -237,7 +240,11 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
     A.fpx = A.fpy = A.fvx = A.fvy = 0.0f;
     A.seed = ii * 12u + P.frame_time * 69u;                             // compute.wgsl:161
     uint32_t cx, cy;
-    xy_of_point(P, me, &cx, &cy);
+    xy_local(P, me, &cx, &cy);
+    if (P.n_live) {   // slab mode: ghosts (outside the owned columns) are not advanced
+        const int32_t cg = (int32_t)cx + P.col_origin;
+        if (cg < (int32_t)P.own_lo || cg >= (int32_t)P.own_hi) live = false;
+    }
     uint32_t cnt = 0;
 #pragma unroll 1
     for (int oy = -1; oy <= 2; ++oy) {
@@ -394,5 +401,9 @@ void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, 
 }
 
 size_t gap_entry_size() { return sizeof(GapEntry); }
+
+void launch_fill_gaps(hipStream_t st, uint32_t* cs, const void* work, const uint32_t* counter, uint32_t work_cap) {
+    hipLaunchKernelGGL(k_fill_gaps, dim3(1024), dim3(FS_BLOCK), 0, st, cs, (const GapEntry*)work, counter, work_cap);
+}
 
 }  // namespace fsd

@@ -1,0 +1,284 @@
+"""multi.py — multi-GPU slab driver: one process per GPU, 1-D slabs of
+whole cell columns along x, one fixed-size point-to-point message per slab neighbour per
+step (migrating particles + 2-column ghost halo) over RCCL (`torch.distributed`, backend
+"nccl" = RCCL over xGMI).  No collective on the data path; a tiny all-reduce of the column
+histogram every `rebalance_every` steps moves the slab boundaries.
+
+The reference is single-device (src/renderer.rs:108-133): everything here is new.
+
+Layers (so the N>1 logic is testable without GPUs):
+  * `partition_columns`, `rebalance_boundaries`  — pure numpy
+  * `Transport`      — neighbour exchange of byte messages (CUDA tensors on nccl, host
+                       tensors on gloo)
+  * `SlabDriver`     — the per-step protocol, generic over an engine adapter
+  * `HipSlabEngine`  — adapter over the C ABI (`fs_slab_*`); tests inject an oracle adapter
+"""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+
+HEADER_BYTES = 16
+RECORD_BYTES = 16
+
+
+# ----------------------------------------------------------------------------- partition
+def global_columns(positions_x, bounds_x, h):
+    """Global cell column of x (funcs.wgsl:212-214) in f32, for host-side partitioning."""
+    f = np.float32
+    c = np.floor((positions_x.astype(f) + f(bounds_x) * f(0.5)) / f(h))
+    return np.clip(c, 0, 4294967295.0).astype(np.int64) + 1
+
+
+def partition_columns(hist, world, min_cols=4):
+    """Boundaries b[0..world] (b[0]=0, b[world]=len(hist)) giving ~equal particle counts."""
+    gw = len(hist)
+    csum = np.concatenate([[0], np.cumsum(hist.astype(np.int64))])
+    total = csum[-1]
+    b = [0]
+    for r in range(1, world):
+        target = total * r // world
+        c = int(np.searchsorted(csum, target, side="left"))
+        c = max(c, b[-1] + min_cols)
+        c = min(c, gw - (world - r) * min_cols)
+        b.append(c)
+    b.append(gw)
+    return b
+
+
+def rebalance_boundaries(bounds, hist, max_shift, min_cols=4):
+    """Move each interior boundary towards the equal-count partition by at most max_shift columns."""
+    world = len(bounds) - 1
+    ideal = partition_columns(hist, world, min_cols)
+    new = list(bounds)
+    for k in range(1, world):
+        d = int(np.clip(ideal[k] - bounds[k], -max_shift, max_shift))
+        new[k] = bounds[k] + d
+    for k in range(1, world):                      # keep slabs at least min_cols wide
+        new[k] = max(new[k], new[k - 1] + min_cols)
+    for k in range(world - 1, 0, -1):
+        new[k] = min(new[k], new[k + 1] - min_cols)
+    return new
+
+
+# ----------------------------------------------------------------------------- transport
+class Transport:
+    """Exchange one byte message with each slab neighbour (rank-1 = left, rank+1 = right)."""
+
+    def __init__(self, rank, world, message_bytes, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = rank, world
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+        self.device = device            # torch.device("cuda", i) for nccl, None for host (gloo)
+        kw = {"dtype": torch.uint8, "device": device} if device is not None else {"dtype": torch.uint8}
+        self.send_left = torch.zeros(message_bytes, **kw)
+        self.send_right = torch.zeros(message_bytes, **kw)
+        self.recv_left = torch.zeros(message_bytes, **kw)
+        self.recv_right = torch.zeros(message_bytes, **kw)
+
+    def exchange(self):
+        dist = self.dist
+        ops = []
+        if self.right is not None:
+            ops.append(dist.P2POp(dist.isend, self.send_right, self.right))
+            ops.append(dist.P2POp(dist.irecv, self.recv_right, self.right))
+        if self.left is not None:
+            ops.append(dist.P2POp(dist.isend, self.send_left, self.left))
+            ops.append(dist.P2POp(dist.irecv, self.recv_left, self.left))
+        if not ops:
+            return
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()          # nccl: makes the current stream wait; gloo: blocks the host
+
+
+# ----------------------------------------------------------------------------- engines
+class HipSlabEngine:
+    """Adapter over the C ABI.  With a CUDA transport the messages are torch CUDA tensors and
+    the kernels write/read them in place (the sim's stream is made torch's current stream so
+    RCCL orders after the pack and before the unpack).  With a host transport (gloo) the
+    messages are staged through fs_buffer device buffers."""
+
+    def __init__(self, g, settings, bounds, rank, world, capacity, recv_capacity, max_cols, device_index, transport):
+        self.g = g
+        self.sim = g.SlabSimulation(settings, bounds[rank], bounds[rank + 1], rank > 0, rank < world - 1, capacity,
+                                    recv_capacity, max_cols, device=device_index)
+        self.t = transport
+        self.cuda = transport.device is not None
+        if not self.cuda:
+            mb = self.sim.message_bytes
+            self.dev = {k: g.ResizableBuffer(k, np.uint8, mb, device=device_index)
+                        for k in ("send_left", "send_right", "recv_left", "recv_right")}
+
+    @property
+    def message_bytes(self):
+        return self.sim.message_bytes
+
+    def _ptr(self, name):
+        if self.cuda:
+            return C.c_void_p(getattr(self.t, name).data_ptr())
+        return C.c_void_p(self.dev[name].device_ptr)
+
+    def pack(self, tick):
+        self.sim.pack(tick, self._ptr("send_left"), self._ptr("send_right"))
+        if not self.cuda:       # stage device -> host tensors for gloo
+            self.sim.sync()
+            for k in ("send_left", "send_right"):
+                getattr(self.t, k).numpy()[:] = self.dev[k].read()
+
+    def finish(self):
+        if not self.cuda:
+            for k in ("recv_left", "recv_right"):
+                self.dev[k].write(0, getattr(self.t, k).numpy())
+        self.sim.step(self._ptr("recv_left"), self._ptr("recv_right"))
+
+    def set_window(self, lo, hi):
+        self.sim.set_window(lo, hi)
+
+    def column_histogram(self, gw):
+        return self.sim.column_histogram(gw)
+
+    def owned_particles(self):
+        rec, owned = self.sim.download()
+        return rec[owned]
+
+    def counters(self):
+        return self.sim.counters()
+
+    def sync(self):
+        self.sim.sync()
+
+
+class SlabDriver:
+    """Per-step protocol: pack -> neighbour exchange -> finish; optional re-balancing."""
+
+    def __init__(self, engine, transport, bounds, grid_w, rebalance_every=0, max_shift=2):
+        self.e, self.t = engine, transport
+        self.bounds = list(bounds)
+        self.grid_w = grid_w
+        self.rebalance_every, self.max_shift = rebalance_every, max_shift
+        self.steps = 0
+
+    def step(self, tick):
+        self.e.pack(tick)
+        self.t.exchange()
+        self.e.finish()
+        self.steps += 1
+        if self.rebalance_every and self.steps % self.rebalance_every == 0:
+            self.rebalance()
+
+    def rebalance(self):
+        torch, dist = self.t.torch, self.t.dist
+        hist = self.e.column_histogram(self.grid_w).astype(np.int64)
+        th = torch.from_numpy(hist)
+        if self.t.device is not None:
+            th = th.to(self.t.device)
+        dist.all_reduce(th)                       # tiny (grid_w * 8 B), every K steps only
+        hist = th.cpu().numpy()
+        new = rebalance_boundaries(self.bounds, hist, self.max_shift)
+        if new != self.bounds:
+            self.bounds = new
+            self.e.set_window(new[self.t.rank], new[self.t.rank + 1])
+
+
+# ----------------------------------------------------------------------------- setup helpers
+def slab_capacities(n_total, world, grid_h, headroom=1.3):
+    recv = max(4096, 6 * grid_h * 10)                 # migrants + 2 ghost columns, compressed fluid
+    main = int(n_total / world * headroom) + 4 * grid_h * 10 + 4096
+    return main + 2 * recv, recv
+
+
+def initial_owned(g, settings, offset, bounds, rank):
+    """This rank's share of the reference lattice (src/simulation.rs:147-163) + column histogram."""
+    lat = g.reference_lattice(settings, offset)
+    cols = global_columns(lat["position"][:, 0], settings.size.x, settings.smoothing_radius)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    return lat[(cols >= lo) & (cols < hi)]
+
+
+def lattice_histogram(g, settings, offset):
+    lat = g.reference_lattice(settings, offset)
+    cols = global_columns(lat["position"][:, 0], settings.size.x, settings.smoothing_radius)
+    gw = int(np.ceil(np.float32(settings.size.x) / np.float32(settings.smoothing_radius))) + 2
+    return np.bincount(cols, minlength=gw)[:gw].astype(np.int64), gw
+
+
+# ----------------------------------------------------------------------------- bench entry
+def bench_main(args, rank, local_rank, world):
+    """bench.py --gpus N (N > 1): strong scaling of the 16M dam break over N slabs."""
+    import torch
+    import torch.distributed as dist
+    import gpu_fluid_simulation_amd as g
+    from bench import ALG_TOTAL, HBM_PEAK_GBS, WORKLOADS
+
+    backend = os.environ.get("FS_DIST_BACKEND", "nccl")
+    if os.environ.get("FS_FORCE_DEVICE0"):      # single-GPU rehearsal: every rank on device 0 (gloo only)
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                            device_id=torch.device("cuda", local_rank) if backend == "nccl" else None)
+    n = WORKLOADS[args.workload]
+    settings, off, tick = g.dam_break_2d(n)
+    hist, gw = lattice_histogram(g, settings, off)
+    gh = int(np.ceil(np.float32(settings.size.y) / np.float32(settings.smoothing_radius))) + 2
+    bounds = partition_columns(hist, world)
+    cap, recv = slab_capacities(n, world, gh)
+    max_cols = min(gw, 2 * max(bounds[k + 1] - bounds[k] for k in range(world)) + 64)
+    lib = g.load_library()
+    probe = g.SlabSimulation(settings, bounds[rank], bounds[rank + 1], rank > 0, rank < world - 1, cap, recv,
+                             max_cols, device=local_rank)
+    msg_bytes = probe.message_bytes
+    probe.close()
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else None
+    tr = Transport(rank, world, msg_bytes, device=dev)
+    eng = HipSlabEngine(g, settings, bounds, rank, world, cap, recv, max_cols, local_rank, tr)
+    eng.sim.upload_owned(initial_owned(g, settings, off, bounds, rank))
+    drv = SlabDriver(eng, tr, bounds, gw, rebalance_every=int(os.environ.get("FS_REBALANCE_EVERY", "64")))
+
+    ext = torch.cuda.ExternalStream(eng.sim.stream_ptr, device=torch.device("cuda", local_rank))
+    with torch.cuda.stream(ext):
+        for _ in range(args.warmup):
+            drv.step(tick)
+        eng.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            drv.step(tick)
+        eng.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dev is not None else "cpu")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    cnt = eng.counters()
+    bad = torch.tensor([cnt["lost"] + cnt["overflow"] + cnt["far_halo"]], dtype=torch.int64,
+                       device=dev if dev is not None else "cpu")
+    dist.all_reduce(bad)
+    nlive = torch.tensor([int(eng.owned_particles().shape[0])], dtype=torch.int64,
+                         device=dev if dev is not None else "cpu")
+    dist.all_reduce(nlive)
+    if rank == 0:
+        ms_per_step = float(tmax.item()) * 1e3 / args.steps
+        value = n / (ms_per_step * 1e-3) / 1e6
+        agg = ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "M particle-steps/s", "value": round(value, 2), "unit": "M particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "particles": n, "scene": "SURVEY.md §8d dam_break_2d",
+                       "sort": "bitonic", "parallelism": f"{world} column slabs, RCCL p2p halo ({backend})",
+                       "slab_columns": [bounds[k + 1] - bounds[k] for k in range(world)],
+                       "message_bytes": msg_bytes},
+            "roofline": {"bound": "hbm", "kernel": "whole step (aggregate over GPUs)", "achieved": round(agg, 1),
+                         "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(agg / (HBM_PEAK_GBS * world), 4),
+                         "traffic": None},
+            "checks": {"particles_conserved": int(nlive.item()) == n, "protocol_violations": int(bad.item())},
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -200,6 +200,45 @@ fs_status fs_profile_read(fs_sim* sim, double ms[FS_PASS_COUNT], uint64_t* steps
 /* Time `steps` consecutive fs_step calls with one hipEvent pair on the stream. */
 fs_status fs_timed_steps(fs_sim* sim, const fs_tick_settings* tick, uint32_t steps, double* ms_total);
 
+/* ------------------------------------------------ multi-GPU slab mode (build extension) */
+/* NOT in the reference (single wgpu device, src/renderer.rs:108-133).  SURVEY.md §8e: a rank
+ * owns the global cell columns [own_lo, own_hi) of the grid (src/simulation.rs:140-141) and
+ * exchanges one fixed-size message per neighbour per step (migrants + 2-column ghost halo).
+ * Messages are device buffers of fs_slab_message_bytes(); the caller moves them between
+ * ranks (RCCL send/recv).  A step = fs_slab_pack -> exchange -> fs_slab_step, all
+ * asynchronous on the simulation's stream; counts stay on the device. */
+typedef struct fs_slab_config {
+    uint32_t own_lo, own_hi;      /* owned window in global cell columns */
+    uint32_t has_left, has_right; /* neighbours present */
+    uint32_t capacity;            /* particle slots of the local array (incl. 2*recv_capacity) */
+    uint32_t recv_capacity;       /* records per incoming message */
+    uint32_t max_cols;            /* widest owned window this handle must support (re-balancing) */
+    uint32_t reserved;
+} fs_slab_config;
+
+typedef struct fs_slab_counters {
+    uint32_t n_live;        /* live slots after the last step (owned + ghosts) */
+    uint32_t lost;          /* particles that left slab + halo in one step (must stay 0) */
+    uint32_t overflow;      /* message or slot capacity exceeded (must stay 0) */
+    uint32_t far_halo;      /* migrants that landed in the receiver's far halo zone (must stay 0) */
+} fs_slab_counters;
+
+fs_status fs_slab_create(const fs_settings* global_settings, int device, const fs_slab_config* cfg, fs_sim** out);
+/* Initial owned particles (host AoS records, any order). */
+fs_status fs_slab_upload_owned(fs_sim* sim, const fs_particle* src, size_t n);
+/* Move the owned window (re-balancing); takes effect at the next fs_slab_pack. */
+fs_status fs_slab_set_window(fs_sim* sim, uint32_t own_lo, uint32_t own_hi);
+size_t fs_slab_message_bytes(const fs_sim* sim);
+/* Begin a step: predict, classify, fill the two outgoing device messages (NULL = no neighbour). */
+fs_status fs_slab_pack(fs_sim* sim, const fs_tick_settings* tick, void* send_left, void* send_right);
+/* Finish the step with the two incoming device messages (NULL = no neighbour). */
+fs_status fs_slab_step(fs_sim* sim, const void* recv_left, const void* recv_right);
+fs_status fs_slab_counters_read(fs_sim* sim, fs_slab_counters* out);   /* blocking */
+/* Live records (global cell keys) and their owned flags; blocking.  Returns n_live. */
+fs_status fs_slab_download(fs_sim* sim, fs_particle* dst, uint8_t* owned, size_t cap, uint32_t* n_live);
+/* Per-global-column particle counts of the owned columns (others untouched); blocking. */
+fs_status fs_slab_column_histogram(fs_sim* sim, uint32_t* hist, size_t grid_w_global);
+
 /* ------------------------------------------------------- ResizableBuffer */
 /* ResizableBuffer<T>::new (src/buffer.rs:27-43). */
 fs_status fs_buffer_create(int device, size_t elem_size, size_t len, const char* name, fs_buffer** out);

@@ -1,0 +1,100 @@
+"""N>1 path on CPU: pure partition logic + a world_size-2 gloo run of multi.SlabDriver /
+multi.Transport with the oracle-backed engine, compared with the single-domain oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_equal_counts(fs):
+    from gpu_fluid_simulation_amd import multi
+    st, off, tick = fs.dam_break_2d(4096)
+    hist, gw = multi.lattice_histogram(fs, st, off)
+    assert gw == 66 and hist.sum() == 4096
+    for world in (1, 2, 4, 8):
+        b = multi.partition_columns(hist, world)
+        assert b[0] == 0 and b[-1] == gw and all(b[k + 1] - b[k] >= 4 for k in range(world))
+        counts = [hist[b[k]:b[k + 1]].sum() for k in range(world)]
+        assert sum(counts) == 4096
+        assert max(counts) <= 4096 / world + 2 * hist.max()
+
+
+def test_rebalance_moves_towards_ideal(fs):
+    from gpu_fluid_simulation_amd import multi
+    hist = np.zeros(100, dtype=np.int64)
+    hist[10:60] = 100
+    b = [0, 50, 100]                      # ideal boundary is column 35
+    nb = multi.rebalance_boundaries(b, hist, max_shift=3)
+    assert nb == [0, 47, 100]
+    for _ in range(10):
+        nb = multi.rebalance_boundaries(nb, hist, max_shift=3)
+    assert nb[1] == 35
+
+
+def test_global_columns_match_oracle_keys(fs, orc):
+    from gpu_fluid_simulation_amd import multi
+    st, off, tick = fs.dam_break_2d(4096)
+    o = orc.OracleSim(st, off)
+    o.step(tick)
+    p = o.particles()
+    gw, gh = o.grid_dims
+    cols = multi.global_columns(p["predicted_position"][:, 0], st.size.x, st.smoothing_radius)
+    assert np.array_equal(cols, (p["grid"] % gw).astype(np.int64))
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import gpu_fluid_simulation_amd as g
+from gpu_fluid_simulation_amd import multi
+from oracle import oracle as O
+from tests.slab_oracle import OracleSlabEngine
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n, steps = int(sys.argv[2]), int(sys.argv[3])
+st, off, tick = g.dam_break_2d(n)
+hist, gw = multi.lattice_histogram(g, st, off)
+bounds = multi.partition_columns(hist, world)
+tr = multi.Transport(rank, world, multi.HEADER_BYTES + multi.RECORD_BYTES * 4096)
+eng = OracleSlabEngine(O, st, bounds, rank, world, tr)
+eng.upload_owned(multi.initial_owned(g, st, off, bounds, rank))
+drv = multi.SlabDriver(eng, tr, bounds, gw, rebalance_every=4, max_shift=1)
+for _ in range(steps):
+    drv.step(tick)
+own = eng.owned_particles()
+np.save(os.path.join(sys.argv[4], f"owned_{rank}.npy"), own)
+for _ in range(int(sys.argv[5])):
+    drv.step(tick)
+np.save(os.path.join(sys.argv[4], f"late_{rank}.npy"), eng.owned_particles())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_world_slabs_match_single_domain(fs, orc, tmp_path, world):
+    n, steps, more = 1024, 5, 11
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + world), WORLD_SIZE=str(world),
+               OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n), str(steps), str(tmp_path), str(more)],
+                              env=dict(env, RANK=str(r)), cwd=ROOT) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.concatenate([np.load(tmp_path / f"owned_{r}.npy") for r in range(world)])
+    st, off, tick = fs.dam_break_2d(n)
+    ref = orc.OracleSim(st, off, ref_quirks=False)
+    for _ in range(steps):
+        ref.step(tick)
+    from tests.slab_oracle import assert_statistics_close, match_and_compare
+    match_and_compare(got, ref.particles(), st.smoothing_radius)          # elementwise while ULP noise is small
+    late = np.concatenate([np.load(tmp_path / f"late_{r}.npy") for r in range(world)])
+    for _ in range(more):
+        ref.step(tick)
+    assert_statistics_close(late, ref.particles(), n)                     # then statistics (chaotic scene)

@@ -1,0 +1,127 @@
+"""HIP slab engine (fs_slab_*) on the GPU: several slabs of one scene, all on device 0,
+exchanging their device messages directly, compared with the single-GPU engine (tolerance
+parity: SURVEY §8e) — plus a 2-process gloo rehearsal of bench.py's multi-rank path."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class InProcessSlabs:
+    def __init__(self, fs, settings, off, world, cap, recv, seed=None, vel=1.0):
+        from gpu_fluid_simulation_amd import multi
+        self.fs, self.multi, self.world = fs, multi, world
+        lat = fs.reference_lattice(settings, off)
+        if seed is not None:
+            rng = np.random.default_rng(seed)
+            lat["position"] += rng.uniform(-0.025, 0.025, size=lat["position"].shape).astype(np.float32)
+            lat["predicted_position"] = lat["position"]
+            lat["velocity"] = rng.uniform(-vel, vel, size=lat["velocity"].shape).astype(np.float32)
+        self.initial = lat
+        cols = multi.global_columns(lat["position"][:, 0], settings.size.x, settings.smoothing_radius)
+        self.gw = int(np.ceil(np.float32(settings.size.x) / np.float32(settings.smoothing_radius))) + 2
+        hist = np.bincount(cols, minlength=self.gw)[: self.gw]
+        self.bounds = multi.partition_columns(hist, world)
+        self.sims, self.bufs = [], []
+        for r in range(world):
+            s = fs.SlabSimulation(settings, self.bounds[r], self.bounds[r + 1], r > 0, r < world - 1, cap, recv,
+                                  max_cols=self.gw, device=0)
+            s.upload_owned(lat[(cols >= self.bounds[r]) & (cols < self.bounds[r + 1])])
+            self.sims.append(s)
+            self.bufs.append({k: fs.ResizableBuffer(k, np.uint8, s.message_bytes) for k in ("sl", "sr")})
+
+    def step(self, tick):
+        P = lambda b: C.c_void_p(b.device_ptr)
+        for r, s in enumerate(self.sims):
+            s.pack(tick, P(self.bufs[r]["sl"]), P(self.bufs[r]["sr"]))
+        for s in self.sims:
+            s.sync()                                  # messages complete before a neighbour reads them
+        for r, s in enumerate(self.sims):
+            left = P(self.bufs[r - 1]["sr"]) if r > 0 else None
+            right = P(self.bufs[r + 1]["sl"]) if r < self.world - 1 else None
+            s.step(left, right)
+        for s in self.sims:
+            s.sync()
+
+    def rebalance(self, max_shift):
+        hist = np.zeros(self.gw, dtype=np.int64)
+        for s in self.sims:
+            hist += s.column_histogram(self.gw)
+        new = self.multi.rebalance_boundaries(self.bounds, hist, max_shift)
+        for r, s in enumerate(self.sims):
+            s.set_window(new[r], new[r + 1])
+        self.bounds = new
+        return hist
+
+    def owned(self):
+        out = []
+        for s in self.sims:
+            rec, own = s.download()
+            out.append(rec[own])
+        return np.concatenate(out)
+
+    def assert_clean(self):
+        for s in self.sims:
+            c = s.counters()
+            assert c["lost"] == 0 and c["overflow"] == 0 and c["far_halo"] == 0, c
+
+
+@pytest.mark.parametrize("world,n,seed", [(2, 4096, None), (3, 4096, 7), (4, 16384, 3)])
+def test_slabs_match_single_gpu(fs, world, n, seed):
+    from tests.slab_oracle import assert_statistics_close, match_and_compare
+    st, off, tick = fs.dam_break_2d(n)
+    slabs = InProcessSlabs(fs, st, off, world, cap=n + 4 * 2048, recv=2048, seed=seed)
+    single = fs.FluidSimulation(st, device=0, initial_offset=off, ref_quirks=False)
+    single.upload_particles(slabs.initial)
+    assert slabs.owned().shape[0] == n
+    for s in range(24):
+        slabs.step(tick)
+        single.tick(tick)
+        if s in (0, 4):
+            slabs.assert_clean()
+            match_and_compare(slabs.owned(), single.download_particles(), st.smoothing_radius)
+    slabs.assert_clean()
+    assert_statistics_close(slabs.owned(), single.download_particles(), n)
+
+
+def test_slab_rebalancing_keeps_parity_and_conserves(fs):
+    from tests.slab_oracle import assert_statistics_close, match_and_compare
+    n = 16384
+    st, off, tick = fs.dam_break_2d(n)
+    slabs = InProcessSlabs(fs, st, off, 4, cap=n + 4 * 4096, recv=4096, seed=11, vel=3.0)
+    single = fs.FluidSimulation(st, device=0, initial_offset=off, ref_quirks=False)
+    single.upload_particles(slabs.initial)
+    b0 = list(slabs.bounds)
+    for s in range(40):
+        slabs.step(tick)
+        single.tick(tick)
+        if s % 2 == 1:
+            hist = slabs.rebalance(max_shift=1)
+            assert hist.sum() == n                      # column histogram sees every owned particle once
+        if s == 5:                                      # boundaries have moved three times by now
+            match_and_compare(slabs.owned(), single.download_particles(), st.smoothing_radius)
+    slabs.assert_clean()
+    assert_statistics_close(slabs.owned(), single.download_particles(), n)
+
+
+def test_two_rank_bench_rehearsal_gloo(fs):
+    """bench.py --gpus 2 launched as two ranks that share GPU 0 (RCCL refuses two ranks on one
+    device, so the rehearsal uses gloo with host-staged messages; the driver's real run uses nccl)."""
+    env = dict(os.environ, FS_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--workload", "dam_break_2d_1M", "--no-cpu-baseline"]
+    env["FS_FORCE_DEVICE0"] = "1"
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["checks"]["particles_conserved"] and d["checks"]["protocol_violations"] == 0
