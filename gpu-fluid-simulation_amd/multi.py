@@ -228,14 +228,11 @@ def bench_main(args, rank, local_rank, world):
     bounds = partition_columns(hist, world)
     cap, recv = slab_capacities(n, world, gh)
     max_cols = min(gw, 2 * max(bounds[k + 1] - bounds[k] for k in range(world)) + 64)
-    lib = g.load_library()
-    probe = g.SlabSimulation(settings, bounds[rank], bounds[rank + 1], rank > 0, rank < world - 1, cap, recv,
-                             max_cols, device=local_rank)
-    msg_bytes = probe.message_bytes
-    probe.close()
+    msg_bytes = HEADER_BYTES + RECORD_BYTES * recv
     dev = torch.device("cuda", local_rank) if backend == "nccl" else None
     tr = Transport(rank, world, msg_bytes, device=dev)
     eng = HipSlabEngine(g, settings, bounds, rank, world, cap, recv, max_cols, local_rank, tr)
+    assert eng.message_bytes == msg_bytes
     eng.sim.upload_owned(initial_owned(g, settings, off, bounds, rank))
     drv = SlabDriver(eng, tr, bounds, gw, rebalance_every=int(os.environ.get("FS_REBALANCE_EVERY", "64")))
 
