@@ -22,49 +22,171 @@ namespace fsd {
 #define SORT_T (1u << SORT_LOG_T)
 #define SORT_THREADS 256
 
-__device__ __forceinline__ void cmpx_lds(u64* s, uint32_t lo, uint32_t hi, uint32_t base, uint32_t n) {
-    if (base + hi >= n) return;
-    const u64 a = s[lo], b = s[hi];
-    if ((uint32_t)(a >> 32) > (uint32_t)(b >> 32)) { s[lo] = b; s[hi] = a; }
+// ------------------------------------------------------------------ tile-local kernels
+// Register-blocked: 256 threads x 16 elements.  The 12 index bits of a tile are split in
+// three groups of four; a thread holds the 16 elements that differ in ONE group, so four
+// consecutive steps run in VGPRs, and the tile is re-distributed through LDS between
+// groups (instead of one LDS round trip per step):
+//   L1: in-thread bits 11..8   idx = (r << 8) | t          (also the coalesced global layout)
+//   L2: in-thread bits  7..4   idx = (t>>4 << 8) | (r << 4) | (t & 15)
+//   L3: in-thread bits  3..0   idx = (t << 4) | r          (16 contiguous elements)
+// LDS addresses are padded by one element per 16 (lt_pad), which makes the 8-byte
+// accesses of all three layouts bank-conflict free (64 x 4-B banks, MI355X guide §LDS).
+// The mirror step of stage s is done as in k_bitonic_strided: rows with bit s set are read
+// from idx ^ (2^s - 1), after which it is a plain distance-2^s step and the remaining steps
+// of that round compare in reversed order on those rows.
+#define LT_E 16
+
+__device__ __forceinline__ uint32_t lt_pad(uint32_t idx) { return idx + (idx >> 4); }
+#define LT_LDS_ELEMS (SORT_T + (SORT_T >> 4))
+
+template <int B>
+__device__ __forceinline__ uint32_t lt_idx(uint32_t r, uint32_t t) {
+    if (B == 8) return (r << 8) | t;
+    if (B == 4) return ((t >> 4) << 8) | (r << 4) | (t & 15u);
+    return (t << 4) | r;
 }
 
-// One step over the tile held in LDS.  sh = stage - step (gw = 1 << sh).
-__device__ __forceinline__ void local_step(u64* s, uint32_t sh, bool flip, uint32_t base, uint32_t n) {
-    const uint32_t gw = 1u << sh;
+__device__ __forceinline__ void lt_cx(u64& lo, u64& hi) {     // lo = physically lower element
+    if ((uint32_t)(lo >> 32) > (uint32_t)(hi >> 32)) { const u64 t = lo; lo = hi; hi = t; }
+}
+
+// Steps on in-thread bits TOP..0 of group B.  FLIP: the step on bit TOP is a stage's mirror step.
+template <int TOP, bool FLIP>
+__device__ __forceinline__ void lt_round(u64 (&x)[LT_E]) {
 #pragma unroll
-    for (uint32_t m = 0; m < SORT_T / 2 / SORT_THREADS; ++m) {
-        const uint32_t p = threadIdx.x + m * SORT_THREADS;
-        const uint32_t lo = ((p >> sh) << (sh + 1)) | (p & (gw - 1));
-        const uint32_t hi = flip ? (lo ^ ((gw << 1) - 1u)) : (lo | gw);
-        cmpx_lds(s, lo, hi, base, n);
+    for (int b = TOP; b >= 0; --b) {
+#pragma unroll
+        for (int r = 0; r < LT_E; ++r) {
+            if (r & (1 << b)) continue;
+            const int r1 = r | (1 << b);
+            if (FLIP && b < TOP && ((r >> TOP) & 1)) lt_cx(x[r1], x[r]);   // reversed rows (see header)
+            else lt_cx(x[r], x[r1]);
+        }
     }
+}
+
+template <int B, int TOP, bool FLIP>
+__device__ __forceinline__ void lt_read(const u64* s, u64 (&x)[LT_E], uint32_t t) {
+#pragma unroll
+    for (int r = 0; r < LT_E; ++r) {
+        uint32_t idx = lt_idx<B>((uint32_t)r, t);
+        if (FLIP && ((r >> TOP) & 1)) idx ^= (1u << (B + TOP)) - 1u;
+        x[r] = s[lt_pad(idx)];
+    }
+}
+
+template <int B, int TOP, bool FLIP>
+__device__ __forceinline__ void lt_write(u64* s, const u64 (&x)[LT_E], uint32_t t) {
+#pragma unroll
+    for (int r = 0; r < LT_E; ++r) {
+        uint32_t idx = lt_idx<B>((uint32_t)r, t);
+        if (FLIP && ((r >> TOP) & 1)) idx ^= (1u << (B + TOP)) - 1u;
+        s[lt_pad(idx)] = x[r];
+    }
+}
+
+// Stage S (0..3) entirely on in-thread bits of L3.
+template <int S>
+__device__ __forceinline__ void lt_stage_regs(u64 (&x)[LT_E]) {
+#pragma unroll
+    for (int r = 0; r < LT_E; ++r) {
+        if (r & (1 << S)) continue;
+        lt_cx(x[r], x[r ^ ((2 << S) - 1)]);          // mirror inside the 2^(S+1) block
+    }
+    if (S > 0) lt_round<(S > 0 ? S - 1 : 0), false>(x);
+}
+
+// Stage S in 4..7: mirror + steps down to bit 4 in L2, then bits 3..0 in L3.
+template <int S>
+__device__ __forceinline__ void lt_stage_mid(u64* s, u64 (&x)[LT_E], uint32_t t) {
+    lt_write<0, 3, false>(s, x, t);
     __syncthreads();
+    lt_read<4, S - 4, true>(s, x, t);
+    lt_round<S - 4, true>(x);
+    lt_write<4, S - 4, true>(s, x, t);
+    __syncthreads();
+    lt_read<0, 3, false>(s, x, t);
+    lt_round<3, false>(x);
+}
+
+// Stage S in 8..11: mirror + steps down to bit 8 in L1, bits 7..4 in L2, bits 3..0 in L3.
+template <int S>
+__device__ __forceinline__ void lt_stage_high(u64* s, u64 (&x)[LT_E], uint32_t t) {
+    lt_write<0, 3, false>(s, x, t);
+    __syncthreads();
+    lt_read<8, S - 8, true>(s, x, t);
+    lt_round<S - 8, true>(x);
+    lt_write<8, S - 8, true>(s, x, t);
+    __syncthreads();
+    lt_read<4, 3, false>(s, x, t);
+    lt_round<3, false>(x);
+    lt_write<4, 3, false>(s, x, t);
+    __syncthreads();
+    lt_read<0, 3, false>(s, x, t);
+    lt_round<3, false>(x);
+}
+
+__device__ __forceinline__ void lt_store_l3(u64* __restrict__ pairs, const u64 (&x)[LT_E], uint32_t base,
+                                            uint32_t t, uint32_t n) {
+    const uint32_t g0 = base + (t << 4);
+    if (g0 + LT_E <= n) {
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(pairs + g0);      // 128-B aligned
+#pragma unroll
+        for (int r = 0; r < LT_E; r += 2) dst[r >> 1] = make_ulonglong2(x[r], x[r + 1]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < LT_E; ++r)
+            if (g0 + r < n) pairs[g0 + r] = x[r];
+    }
 }
 
 template <bool INIT>
 __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict__ pairs, uint32_t n,
                                                                 uint32_t num_stages) {
-    __shared__ u64 s[SORT_T];
+    __shared__ u64 s[LT_LDS_ELEMS];
     const uint32_t base = blockIdx.x * SORT_T;
-#pragma unroll
-    for (uint32_t m = 0; m < SORT_T / SORT_THREADS; ++m) {
-        const uint32_t j = threadIdx.x + m * SORT_THREADS;
-        s[j] = (base + j < n) ? pairs[base + j] : ~0ull;
-    }
-    __syncthreads();
+    const uint32_t t = threadIdx.x;
+    u64 x[LT_E];
     if (INIT) {
-        for (uint32_t stage = 0; stage < num_stages; ++stage) {
-            local_step(s, stage, true, base, n);                       // step 0: mirrored compare
-            for (uint32_t step = 1; step <= stage; ++step) local_step(s, stage - step, false, base, n);
-        }
-    } else {
-        for (int sh = SORT_LOG_T - 1; sh >= 0; --sh) local_step(s, (uint32_t)sh, false, base, n);
-    }
+        // coalesced load, straight into LDS, then the L3 view
 #pragma unroll
-    for (uint32_t m = 0; m < SORT_T / SORT_THREADS; ++m) {
-        const uint32_t j = threadIdx.x + m * SORT_THREADS;
-        if (base + j < n) pairs[base + j] = s[j];
+        for (int r = 0; r < LT_E; ++r) {
+            const uint32_t j = ((uint32_t)r << 8) | t;
+            s[lt_pad(j)] = (base + j < n) ? pairs[base + j] : ~0ull;
+        }
+        __syncthreads();
+        lt_read<0, 3, false>(s, x, t);
+        lt_stage_regs<0>(x);
+        if (num_stages > 1) lt_stage_regs<1>(x);
+        if (num_stages > 2) lt_stage_regs<2>(x);
+        if (num_stages > 3) lt_stage_regs<3>(x);
+        if (num_stages > 4) lt_stage_mid<4>(s, x, t);
+        if (num_stages > 5) lt_stage_mid<5>(s, x, t);
+        if (num_stages > 6) lt_stage_mid<6>(s, x, t);
+        if (num_stages > 7) lt_stage_mid<7>(s, x, t);
+        if (num_stages > 8) lt_stage_high<8>(s, x, t);
+        if (num_stages > 9) lt_stage_high<9>(s, x, t);
+        if (num_stages > 10) lt_stage_high<10>(s, x, t);
+        if (num_stages > 11) lt_stage_high<11>(s, x, t);
+    } else {
+        // tail of a stage >= 12: plain steps on bits 11..0; the L1 view IS the coalesced global layout
+#pragma unroll
+        for (int r = 0; r < LT_E; ++r) {
+            const uint32_t j = ((uint32_t)r << 8) | t;
+            x[r] = (base + j < n) ? pairs[base + j] : ~0ull;
+        }
+        lt_round<3, false>(x);
+        lt_write<8, 3, false>(s, x, t);
+        __syncthreads();
+        lt_read<4, 3, false>(s, x, t);
+        lt_round<3, false>(x);
+        lt_write<4, 3, false>(s, x, t);
+        __syncthreads();
+        lt_read<0, 3, false>(s, x, t);
+        lt_round<3, false>(x);
     }
+    lt_store_l3(pairs, x, base, t, n);
 }
 
 // M consecutive global steps of one stage in ONE pass, register-blocked: a thread owns the
