@@ -137,36 +137,109 @@ __device__ __forceinline__ bool row_range(const StepParams& P, const uint32_t* _
     return a < b;
 }
 
+// ------------------------------------------------------------ block neighbour tiles
+// A workgroup owns 256 consecutive sorted particles (a strip of cells in one grid row), so
+// the candidates of ALL its lanes for sweep row r form one short contiguous index range
+// [blo_r, bhi_r).  The three ranges are staged into LDS with coalesced loads once and the
+// per-lane loops then read LDS instead of issuing one gather per candidate.  Strips that
+// straddle a grid-row end (or very sparse ones) exceed the tile and take the global path.
+#define NB_TILE 640          // staged candidates per sweep row
+
+struct RowRanges { uint32_t lo[3], hi[3]; };
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+
+// Block-wide [min lo, max hi) per sweep row; returns true when all three fit the tile.
+__device__ __forceinline__ bool block_tile_bounds(const RowRanges& R, uint32_t* s_red /*[24]*/, uint32_t* blo,
+                                                  uint32_t* bhi) {
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const bool has = R.lo[r] < R.hi[r];
+        const uint32_t mn = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
+        const uint32_t mx = wave_max_u32(has ? R.hi[r] : 0u);
+        if (lane == 0) { s_red[(r * 2) * 4 + w] = mn; s_red[(r * 2 + 1) * 4 + w] = mx; }
+    }
+    __syncthreads();
+    bool fit = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        uint32_t mn = s_red[(r * 2) * 4], mx = s_red[(r * 2 + 1) * 4];
+#pragma unroll
+        for (int k = 1; k < FS_BLOCK / 64; ++k) {
+            const uint32_t a = s_red[(r * 2) * 4 + k], b = s_red[(r * 2 + 1) * 4 + k];
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        if (mx <= mn) { mn = 0; mx = 0; }
+        blo[r] = mn; bhi[r] = mx;
+        fit = fit && (mx - mn <= NB_TILE);
+    }
+    return fit;
+}
+
 // -------------------------------------------------------------------- density
+__device__ __forceinline__ float density_term(const StepParams& P, float h2, float2 me, float2 q) {
+    const float dx = q.x - me.x, dy = q.y - me.y;
+    const float r2 = dx * dx + dy * dy;
+    float kern = 0.0f;
+    if (!(r2 > h2)) {
+        const float diff = h2 - r2;
+        kern = P.poly6_norm * diff * diff * diff;       // funcs.wgsl:77
+    }
+    return P.mass * kern * 1.0f;                        // funcs.wgsl:192
+}
+
 __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2* __restrict__ pred,
                                                       const uint32_t* __restrict__ cs,
                                                       const uint32_t* __restrict__ start_ref,
                                                       const u64* __restrict__ pairs, float* __restrict__ rho_out) {
+    __shared__ float2 s_pred[3][NB_TILE];
+    __shared__ uint32_t s_red[24];
     const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
     const uint32_t n = P.n_live ? *P.n_live : P.n;
-    if (i >= n) return;
+    if (blockIdx.x * FS_BLOCK >= n) return;                 // whole block dead (uniform)
+    const bool live = i < n;
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
-    const float2 me = pred[i];
+    const float2 me = pred[live ? i : n - 1];
     uint32_t cx, cy;
     xy_local(P, me, &cx, &cy);
     const float h2 = P.h * P.h;     // funcs.wgsl:73
-    float rho = 0.0f;
-#pragma unroll 1
-    for (int oy = -1; oy <= 1; ++oy) {
-        uint32_t lo, hi;
-        if (!row_range(P, cs, cx, cy + (uint32_t)oy, lo_fix, &lo, &hi)) continue;
-        for (uint32_t k = lo; k < hi; ++k) {
-            const float2 q = pred[k];
-            const float dx = q.x - me.x, dy = q.y - me.y;
-            const float r2 = dx * dx + dy * dy;
-            float kern = 0.0f;
-            if (!(r2 > h2)) {
-                const float diff = h2 - r2;
-                kern = P.poly6_norm * diff * diff * diff;       // funcs.wgsl:77
-            }
-            rho += P.mass * kern * 1.0f;                        // funcs.wgsl:192
-        }
+    RowRanges R;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        R.lo[r] = 0; R.hi[r] = 0;
+        if (live) (void)row_range(P, cs, cx, cy + (uint32_t)(r - 1), lo_fix, &R.lo[r], &R.hi[r]);
+        if (R.hi[r] < R.lo[r]) R.hi[r] = R.lo[r];
     }
+    uint32_t blo[3], bhi[3];
+    const bool fit = block_tile_bounds(R, s_red, blo, bhi);
+    float rho = 0.0f;
+    if (fit) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            for (uint32_t j = threadIdx.x; j < bhi[r] - blo[r]; j += FS_BLOCK) s_pred[r][j] = pred[blo[r] + j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t b0 = blo[r];
+            for (uint32_t k = R.lo[r]; k < R.hi[r]; ++k) rho += density_term(P, h2, me, s_pred[r][k - b0]);
+        }
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < 3; ++r)
+            for (uint32_t k = R.lo[r]; k < R.hi[r]; ++k) rho += density_term(P, h2, me, pred[k]);
+    }
+    if (!live) return;
     rho = fmaxf(rho, 1.19209290e-07f);                          // funcs.wgsl:202
     rho_out[i] = fmaxf(rho, 0.1f);                              // compute.wgsl:70
 }
@@ -178,7 +251,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
 //   heavy — pressure + viscosity terms for the listed neighbours, accumulated in list order,
 //           which is the reference visiting order, so sums keep their association.
 // A full list (FORCE_CAP) is flushed wave-uniformly and scanning resumes.
-#define FORCE_CAP 32
+#define FORCE_CAP 24
 
 struct ForceAcc { float fpx, fpy, fvx, fvy; uint32_t seed; };
 
@@ -217,6 +290,69 @@ __device__ __forceinline__ void force_pair(const StepParams& P, const float2 me,
     A.fvy += __fdiv_rn(nv.y - mv.y, nrho) * kv;
 }
 
+#define NBF_TILE 448         // staged candidates per sweep row in k_force
+#ifndef FS_FORCE_STAGE_ALL
+#define FS_FORCE_STAGE_ALL 0 // 1: stage pred + vel + rho (20 B/candidate); 0: pred only, vel/rho gathered in the heavy phase
+#endif
+
+template <bool STAGED>
+__device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges& R, const uint32_t* blo,
+                                            uint32_t ii, bool live, const float2 me, const float2 mv, float pressure,
+                                            const float2* __restrict__ pred, const float2* __restrict__ vel_s,
+                                            const float* __restrict__ rho, const float2 (*s_pred)[NBF_TILE],
+                                            const float2 (*s_vel)[NBF_TILE], const float (*s_rho)[NBF_TILE],
+                                            uint32_t* s_list, ForceAcc& A) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t cnt = 0;
+#pragma unroll 1
+    for (int r = 0; r <= 3; ++r) {
+        // 4th trip only flushes; selects instead of dynamic indexing keep R/blo in registers
+        const uint32_t lo = r == 0 ? R.lo[0] : r == 1 ? R.lo[1] : r == 2 ? R.lo[2] : 0u;
+        const uint32_t hi = r == 0 ? R.hi[0] : r == 1 ? R.hi[1] : r == 2 ? R.hi[2] : 0u;
+        const uint32_t b0 = !STAGED ? 0u : r == 0 ? blo[0] : r == 1 ? blo[1] : r == 2 ? blo[2] : 0u;
+        const float2* sp = s_pred[r < 3 ? r : 0];
+        uint32_t k = lo;
+        for (;;) {
+            // scan until this lane's row is exhausted or its list is full
+            while (k < hi && cnt < FORCE_CAP) {
+                const float2 q = STAGED ? sp[k - b0] : pred[k];
+                const float ox = q.x - me.x, oyv = q.y - me.y;
+                const float r2 = ox * ox + oyv * oyv;
+                if (k != ii && !(r2 > P.sqr_radius)) {
+                    // staged: remember (row, tile offset); global: the particle index
+                    s_list[cnt * FS_BLOCK + tid] = STAGED ? (((uint32_t)r << 16) | (k - b0)) : k;
+                    ++cnt;
+                }
+                ++k;
+            }
+            const bool full = cnt == FORCE_CAP && k < hi;
+            const bool flush = __any(full) || r > 2;
+            if (flush) {
+                for (uint32_t e = 0; __any(e < cnt); ++e) {
+                    if (e < cnt) {
+                        const uint32_t j = s_list[e * FS_BLOCK + tid];
+                        if (STAGED) {
+                            const uint32_t jr = j >> 16, jo = j & 0xFFFFu;
+#if FS_FORCE_STAGE_ALL
+                            force_pair(P, me, mv, pressure, s_pred[jr][jo], s_vel[jr][jo], s_rho[jr][jo], A);
+#else
+                            const uint32_t jb = jr == 0 ? blo[0] : jr == 1 ? blo[1] : blo[2];
+                            const uint32_t jg = jb + jo;
+                            force_pair(P, me, mv, pressure, s_pred[jr][jo], vel_s[jg], rho[jg], A);
+#endif
+                        } else {
+                            force_pair(P, me, mv, pressure, pred[j], vel_s[j], rho[j], A);
+                        }
+                    }
+                }
+                cnt = 0;
+            }
+            if (!__any(k < hi)) break;
+        }
+    }
+    (void)live;
+}
+
 __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* __restrict__ pos_s,
                                                     const float2* __restrict__ vel_s,
                                                     const float2* __restrict__ pred, const float* __restrict__ rho,
@@ -225,10 +361,19 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
                                                     const u64* __restrict__ pairs, const float2* __restrict__ tex,
                                                     float2* __restrict__ pos_out, float2* __restrict__ vel_out) {
     __shared__ uint32_t s_list[FORCE_CAP * FS_BLOCK];
+    __shared__ float2 s_pred[3][NBF_TILE];
+#if FS_FORCE_STAGE_ALL
+    __shared__ float2 s_vel[3][NBF_TILE];
+    __shared__ float s_rho[3][NBF_TILE];
+#else
+    const float2 (*s_vel)[NBF_TILE] = nullptr;
+    const float (*s_rho)[NBF_TILE] = nullptr;
+#endif
+    __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * FS_BLOCK + tid;
     const uint32_t n = P.n_live ? *P.n_live : P.n;
-    if (n == 0) return;
+    if (blockIdx.x * FS_BLOCK >= n) return;          // whole block dead (uniform)
     bool live = i < n;
     const uint32_t ii = live ? i : n - 1;            // dead lanes shadow the last particle, store nothing
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
@@ -245,35 +390,32 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
         const int32_t cg = (int32_t)cx + P.col_origin;
         if (cg < (int32_t)P.own_lo || cg >= (int32_t)P.own_hi) live = false;
     }
-    uint32_t cnt = 0;
-#pragma unroll 1
-    for (int oy = -1; oy <= 2; ++oy) {
-        uint32_t lo = 0, hi = 0;
-        if (live && oy <= 1) (void)row_range(P, cs, cx, cy + (uint32_t)oy, lo_fix, &lo, &hi);
-        if (oy > 1) hi = lo;                                            // 4th trip only flushes
-        uint32_t k = lo;
-        for (;;) {
-            // scan until this lane's row is exhausted or its list is full
-            while (k < hi && cnt < FORCE_CAP) {
-                const float2 q = pred[k];
-                const float ox = q.x - me.x, oyv = q.y - me.y;
-                const float r2 = ox * ox + oyv * oyv;
-                if (k != ii && !(r2 > P.sqr_radius)) { s_list[cnt * FS_BLOCK + tid] = k; ++cnt; }
-                ++k;
+    RowRanges R;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        R.lo[r] = 0; R.hi[r] = 0;
+        if (live) (void)row_range(P, cs, cx, cy + (uint32_t)(r - 1), lo_fix, &R.lo[r], &R.hi[r]);
+        if (R.hi[r] < R.lo[r]) R.hi[r] = R.lo[r];
+    }
+    uint32_t blo[3], bhi[3];
+    const bool fit = block_tile_bounds(R, s_red, blo, bhi);
+    bool staged = fit;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) staged = staged && (bhi[r] - blo[r] <= NBF_TILE);
+    if (staged) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            for (uint32_t j = tid; j < bhi[r] - blo[r]; j += FS_BLOCK) {
+                s_pred[r][j] = pred[blo[r] + j];
+#if FS_FORCE_STAGE_ALL
+                s_vel[r][j] = vel_s[blo[r] + j];
+                s_rho[r][j] = rho[blo[r] + j];
+#endif
             }
-            const bool full = cnt == FORCE_CAP && k < hi;
-            const bool flush = __any(full) || oy > 1;
-            if (flush) {
-                for (uint32_t e = 0; __any(e < cnt); ++e) {
-                    if (e < cnt) {
-                        const uint32_t j = s_list[e * FS_BLOCK + tid];
-                        force_pair(P, me, mv, pressure, pred[j], vel_s[j], rho[j], A);
-                    }
-                }
-                cnt = 0;
-            }
-            if (!__any(k < hi)) break;
-        }
+        __syncthreads();
+        force_sweep<true>(P, R, blo, ii, live, me, mv, pressure, pred, vel_s, rho, s_pred, s_vel, s_rho, s_list, A);
+    } else {
+        force_sweep<false>(P, R, blo, ii, live, me, mv, pressure, pred, vel_s, rho, s_pred, s_vel, s_rho, s_list, A);
     }
     if (!live) return;
     const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
