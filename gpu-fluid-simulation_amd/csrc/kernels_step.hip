@@ -231,11 +231,22 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const uint32_t b0 = blo[r];
-            for (uint32_t k = R.lo[r]; k < R.hi[r]; ++k) rho += density_term(P, h2, me, s_pred[r][k - b0]);
+            // four candidates per trip: independent LDS reads and kernel evaluations (ILP), then the
+            // four adds in index order; a slot past the range adds +0.0f, an identity since rho >= +0
+            const uint32_t b0 = blo[r], hi = R.hi[r];
+            for (uint32_t k = R.lo[r]; k < hi; k += 4) {
+                const uint32_t last = hi - 1u - b0;
+                const uint32_t o0 = k - b0, o1 = min(o0 + 1u, last), o2 = min(o0 + 2u, last), o3 = min(o0 + 3u, last);
+                const float2 q0 = s_pred[r][o0], q1 = s_pred[r][o1], q2 = s_pred[r][o2], q3 = s_pred[r][o3];
+                const float t0 = density_term(P, h2, me, q0);
+                const float t1 = (k + 1u < hi) ? density_term(P, h2, me, q1) : 0.0f;
+                const float t2 = (k + 2u < hi) ? density_term(P, h2, me, q2) : 0.0f;
+                const float t3 = (k + 3u < hi) ? density_term(P, h2, me, q3) : 0.0f;
+                rho += t0; rho += t1; rho += t2; rho += t3;
+            }
         }
     } else {
-#pragma unroll 1
+#pragma unroll
         for (int r = 0; r < 3; ++r)
             for (uint32_t k = R.lo[r]; k < R.hi[r]; ++k) rho += density_term(P, h2, me, pred[k]);
     }
@@ -254,17 +265,21 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
 #define FORCE_CAP 24
 
 struct ForceAcc { float fpx, fpy, fvx, fvy; uint32_t seed; };
+struct ForceTerms { float px, py, vx, vy; };
 
-__device__ __forceinline__ void force_pair(const StepParams& P, const float2 me, const float2 mv, float pressure,
-                                           const float2 q, const float2 nv, float nrho, ForceAcc& A) {
+// One in-radius neighbour: pressure (compute.wgsl:207-223) and viscosity (:283-288) terms.
+// `seed` only advances on the coincident-particle path (dst == 0, compute.wgsl:211-212).
+__device__ __forceinline__ ForceTerms force_terms(const StepParams& P, const float2 me, const float2 mv,
+                                                  float pressure, const float2 q, const float2 nv, float nrho,
+                                                  uint32_t& seed) {
     const float h = P.h;
     const float ox = q.x - me.x, oyv = q.y - me.y;
     const float r2 = ox * ox + oyv * oyv;
     const float dst = sqrt_rn(r2);                                      // compute.wgsl:207,283
     float dx, dy;
     if (dst == 0.0f) {                                                  // :211-212
-        const float rx = rand_f32(&A.seed);
-        const float ry = rand_f32(&A.seed);
+        const float rx = rand_f32(&seed);
+        const float ry = rand_f32(&seed);
         const float len = sqrt_rn(rx * rx + ry * ry);
         dx = __fdiv_rn(rx, len);
         dy = __fdiv_rn(ry, len);
@@ -275,8 +290,9 @@ __device__ __forceinline__ void force_pair(const StepParams& P, const float2 me,
     const float npress = P.pressure_k * (nrho - P.rest_density);
     const float kern = (dst <= h) ? (-(h - dst)) * P.spiky : 0.0f;      // funcs.wgsl:101-109
     const float shared = (pressure + npress) * 0.5f;
-    A.fpx += __fdiv_rn(dx * kern * shared, nrho);                       // compute.wgsl:223
-    A.fpy += __fdiv_rn(dy * kern * shared, nrho);
+    ForceTerms T;
+    T.px = __fdiv_rn(dx * kern * shared, nrho);                         // compute.wgsl:223
+    T.py = __fdiv_rn(dy * kern * shared, nrho);
     float kv = 0.0f;                                                    // funcs.wgsl:112-123
     if (dst <= h) {
         if (dst == 0.0f) {
@@ -286,8 +302,9 @@ __device__ __forceinline__ void force_pair(const StepParams& P, const float2 me,
                              (__fdiv_rn(h, 2.0f * dst)) - 1.0f);
         }
     }
-    A.fvx += __fdiv_rn(nv.x - mv.x, nrho) * kv;                         // compute.wgsl:288
-    A.fvy += __fdiv_rn(nv.y - mv.y, nrho) * kv;
+    T.vx = __fdiv_rn(nv.x - mv.x, nrho) * kv;                           // compute.wgsl:288
+    T.vy = __fdiv_rn(nv.y - mv.y, nrho) * kv;
+    return T;
 }
 
 #define NBF_TILE 448         // staged candidates per sweep row in k_force
@@ -313,36 +330,60 @@ __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges
         const float2* sp = s_pred[r < 3 ? r : 0];
         uint32_t k = lo;
         for (;;) {
-            // scan until this lane's row is exhausted or its list is full
-            while (k < hi && cnt < FORCE_CAP) {
-                const float2 q = STAGED ? sp[k - b0] : pred[k];
-                const float ox = q.x - me.x, oyv = q.y - me.y;
-                const float r2 = ox * ox + oyv * oyv;
-                if (k != ii && !(r2 > P.sqr_radius)) {
-                    // staged: remember (row, tile offset); global: the particle index
-                    s_list[cnt * FS_BLOCK + tid] = STAGED ? (((uint32_t)r << 16) | (k - b0)) : k;
-                    ++cnt;
+            // scan (4 candidates per trip) until this lane's row is exhausted or its list is nearly full
+            while (k < hi && cnt + 4u <= FORCE_CAP) {
+                const uint32_t last = hi - 1u;
+                const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
+                const float2 q0 = STAGED ? sp[k - b0] : pred[k];
+                const float2 q1 = STAGED ? sp[k1 - b0] : pred[k1];
+                const float2 q2 = STAGED ? sp[k2 - b0] : pred[k2];
+                const float2 q3 = STAGED ? sp[k3 - b0] : pred[k3];
+                const float2 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    const uint32_t ku = k + u;
+                    const float ox = qq[u].x - me.x, oyv = qq[u].y - me.y;
+                    const float r2 = ox * ox + oyv * oyv;
+                    if (ku < hi && ku != ii && !(r2 > P.sqr_radius)) {
+                        // staged: remember (row, tile offset); global: the particle index
+                        s_list[cnt * FS_BLOCK + tid] = STAGED ? (((uint32_t)r << 16) | (ku - b0)) : ku;
+                        ++cnt;
+                    }
                 }
-                ++k;
+                k += 4u;
             }
-            const bool full = cnt == FORCE_CAP && k < hi;
+            if (k > hi) k = hi;
+            const bool full = cnt + 4u > FORCE_CAP && k < hi;
             const bool flush = __any(full) || r > 2;
             if (flush) {
-                for (uint32_t e = 0; __any(e < cnt); ++e) {
+                // heavy phase: two neighbours per trip (independent divide chains in flight), terms
+                // added in list order
+                for (uint32_t e = 0; __any(e < cnt); e += 2u) {
                     if (e < cnt) {
-                        const uint32_t j = s_list[e * FS_BLOCK + tid];
+                        const bool two = e + 1u < cnt;
+                        const uint32_t j0 = s_list[e * FS_BLOCK + tid];
+                        const uint32_t j1 = s_list[(two ? e + 1u : e) * FS_BLOCK + tid];
+                        float2 q0, q1, v0, v1;
+                        float d0, d1;
                         if (STAGED) {
-                            const uint32_t jr = j >> 16, jo = j & 0xFFFFu;
+                            const uint32_t r0 = j0 >> 16, o0 = j0 & 0xFFFFu, r1 = j1 >> 16, o1 = j1 & 0xFFFFu;
+                            q0 = s_pred[r0][o0]; q1 = s_pred[r1][o1];
 #if FS_FORCE_STAGE_ALL
-                            force_pair(P, me, mv, pressure, s_pred[jr][jo], s_vel[jr][jo], s_rho[jr][jo], A);
+                            v0 = s_vel[r0][o0]; d0 = s_rho[r0][o0]; v1 = s_vel[r1][o1]; d1 = s_rho[r1][o1];
 #else
-                            const uint32_t jb = jr == 0 ? blo[0] : jr == 1 ? blo[1] : blo[2];
-                            const uint32_t jg = jb + jo;
-                            force_pair(P, me, mv, pressure, s_pred[jr][jo], vel_s[jg], rho[jg], A);
+                            const uint32_t g0 = (r0 == 0 ? blo[0] : r0 == 1 ? blo[1] : blo[2]) + o0;
+                            const uint32_t g1 = (r1 == 0 ? blo[0] : r1 == 1 ? blo[1] : blo[2]) + o1;
+                            v0 = vel_s[g0]; d0 = rho[g0]; v1 = vel_s[g1]; d1 = rho[g1];
 #endif
                         } else {
-                            force_pair(P, me, mv, pressure, pred[j], vel_s[j], rho[j], A);
+                            q0 = pred[j0]; v0 = vel_s[j0]; d0 = rho[j0];
+                            q1 = pred[j1]; v1 = vel_s[j1]; d1 = rho[j1];
                         }
+                        const ForceTerms T0 = force_terms(P, me, mv, pressure, q0, v0, d0, A.seed);
+                        uint32_t seed1 = A.seed;
+                        const ForceTerms T1 = force_terms(P, me, mv, pressure, q1, v1, d1, seed1);
+                        A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
+                        if (two) { A.fpx += T1.px; A.fpy += T1.py; A.fvx += T1.vx; A.fvy += T1.vy; A.seed = seed1; }
                     }
                 }
                 cnt = 0;
