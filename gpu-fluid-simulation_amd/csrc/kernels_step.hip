@@ -7,6 +7,8 @@
 //                     (compute.wgsl:45-56) + dense cell-start table
 //   k_density       = calculate_density (compute.wgsl:59-74, funcs.wgsl:157-203)
 //   k_force         = move_particle + both force sweeps fused (compute.wgsl:79-299)
+#include <type_traits>
+
 #include "fs_device.h"
 #include "fs_kernels.h"
 
@@ -231,19 +233,20 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            // four candidates per trip: independent LDS reads and kernel evaluations (ILP), then the
-            // four adds in index order; a slot past the range adds +0.0f, an identity since rho >= +0
-            const uint32_t b0 = blo[r], hi = R.hi[r];
-            for (uint32_t k = R.lo[r]; k < hi; k += 4) {
-                const uint32_t last = hi - 1u - b0;
-                const uint32_t o0 = k - b0, o1 = min(o0 + 1u, last), o2 = min(o0 + 2u, last), o3 = min(o0 + 3u, last);
-                const float2 q0 = s_pred[r][o0], q1 = s_pred[r][o1], q2 = s_pred[r][o2], q3 = s_pred[r][o3];
-                const float t0 = density_term(P, h2, me, q0);
-                const float t1 = (k + 1u < hi) ? density_term(P, h2, me, q1) : 0.0f;
-                const float t2 = (k + 2u < hi) ? density_term(P, h2, me, q2) : 0.0f;
-                const float t3 = (k + 3u < hi) ? density_term(P, h2, me, q3) : 0.0f;
+            // four candidates per trip (independent LDS reads and kernel evaluations give the wave
+            // ILP), adds in index order; then a scalar tail
+            const float2* sp = s_pred[r] - 0;
+            const bool any = R.lo[r] < R.hi[r];
+            const uint32_t hi = any ? R.hi[r] - blo[r] : 0u;
+            uint32_t k = any ? R.lo[r] - blo[r] : 0u;
+            for (; k + 4u <= hi; k += 4u) {
+                const float t0 = density_term(P, h2, me, sp[k]);
+                const float t1 = density_term(P, h2, me, sp[k + 1u]);
+                const float t2 = density_term(P, h2, me, sp[k + 2u]);
+                const float t3 = density_term(P, h2, me, sp[k + 3u]);
                 rho += t0; rho += t1; rho += t2; rho += t3;
             }
+            for (; k < hi; ++k) rho += density_term(P, h2, me, sp[k]);
         }
     } else {
 #pragma unroll
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
 //   heavy — pressure + viscosity terms for the listed neighbours, accumulated in list order,
 //           which is the reference visiting order, so sums keep their association.
 // A full list (FORCE_CAP) is flushed wave-uniformly and scanning resumes.
-#define FORCE_CAP 24
+#define FORCE_CAP 24          // neighbour-list entries per lane (u16 when staged, u32 entries = CAP/2 otherwise)
 
 struct ForceAcc { float fpx, fpy, fvx, fvy; uint32_t seed; };
 struct ForceTerms { float px, py, vx, vy; };
@@ -307,53 +310,50 @@ __device__ __forceinline__ ForceTerms force_terms(const StepParams& P, const flo
     return T;
 }
 
-#define NBF_TILE 448         // staged candidates per sweep row in k_force
-#ifndef FS_FORCE_STAGE_ALL
-#define FS_FORCE_STAGE_ALL 0 // 1: stage pred + vel + rho (20 B/candidate); 0: pred only, vel/rho gathered in the heavy phase
-#endif
+#define NBF_TILE 448         // staged candidates (predicted positions) per sweep row in k_force; vel/rho of the
+                             // few in-radius neighbours are gathered in the heavy phase (staging them too cost
+                             // occupancy and measured slower: the kernel is issue-bound, not latency-bound)
 
 template <bool STAGED>
 __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges& R, const uint32_t* blo,
-                                            uint32_t ii, bool live, const float2 me, const float2 mv, float pressure,
+                                            uint32_t ii, const float2 me, const float2 mv, float pressure,
                                             const float2* __restrict__ pred, const float2* __restrict__ vel_s,
                                             const float* __restrict__ rho, const float2 (*s_pred)[NBF_TILE],
-                                            const float2 (*s_vel)[NBF_TILE], const float (*s_rho)[NBF_TILE],
-                                            uint32_t* s_list, ForceAcc& A) {
+                                            unsigned short* s_list16, ForceAcc& A) {
+    typedef typename std::conditional<STAGED, unsigned short, uint32_t>::type entry_t;
+    entry_t* s_list = reinterpret_cast<entry_t*>(s_list16);
+    constexpr uint32_t CAP = STAGED ? FORCE_CAP : FORCE_CAP / 2;     // same LDS bytes either way
     const uint32_t tid = threadIdx.x;
     uint32_t cnt = 0;
 #pragma unroll 1
     for (int r = 0; r <= 3; ++r) {
         // 4th trip only flushes; selects instead of dynamic indexing keep R/blo in registers
-        const uint32_t lo = r == 0 ? R.lo[0] : r == 1 ? R.lo[1] : r == 2 ? R.lo[2] : 0u;
-        const uint32_t hi = r == 0 ? R.hi[0] : r == 1 ? R.hi[1] : r == 2 ? R.hi[2] : 0u;
         const uint32_t b0 = !STAGED ? 0u : r == 0 ? blo[0] : r == 1 ? blo[1] : r == 2 ? blo[2] : 0u;
-        const float2* sp = s_pred[r < 3 ? r : 0];
+        const uint32_t lo = (r == 0 ? R.lo[0] : r == 1 ? R.lo[1] : r == 2 ? R.lo[2] : 0u);
+        const uint32_t hi = (r == 0 ? R.hi[0] : r == 1 ? R.hi[1] : r == 2 ? R.hi[2] : 0u);
+        const float2* sp = s_pred[r < 3 ? r : 0] - (STAGED ? b0 : 0u);   // sp[k] is candidate k of this row
+        const float2* src = STAGED ? sp : pred;
+        const uint32_t tag = STAGED ? (((uint32_t)r << 14) - b0) : 0u;   // entry = tag + k
         uint32_t k = lo;
         for (;;) {
-            // scan (4 candidates per trip) until this lane's row is exhausted or its list is nearly full
-            while (k < hi && cnt + 4u <= FORCE_CAP) {
-                const uint32_t last = hi - 1u;
-                const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
-                const float2 q0 = STAGED ? sp[k - b0] : pred[k];
-                const float2 q1 = STAGED ? sp[k1 - b0] : pred[k1];
-                const float2 q2 = STAGED ? sp[k2 - b0] : pred[k2];
-                const float2 q3 = STAGED ? sp[k3 - b0] : pred[k3];
+            // scan: four candidates per trip while the list has room for all four, then singly
+            for (; k + 4u <= hi && cnt + 4u <= CAP; k += 4u) {
+                const float2 q0 = src[k], q1 = src[k + 1u], q2 = src[k + 2u], q3 = src[k + 3u];
                 const float2 qq[4] = {q0, q1, q2, q3};
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) {
-                    const uint32_t ku = k + u;
                     const float ox = qq[u].x - me.x, oyv = qq[u].y - me.y;
                     const float r2 = ox * ox + oyv * oyv;
-                    if (ku < hi && ku != ii && !(r2 > P.sqr_radius)) {
-                        // staged: remember (row, tile offset); global: the particle index
-                        s_list[cnt * FS_BLOCK + tid] = STAGED ? (((uint32_t)r << 16) | (ku - b0)) : ku;
-                        ++cnt;
-                    }
+                    if (k + u != ii && !(r2 > P.sqr_radius)) { s_list[cnt * FS_BLOCK + tid] = (entry_t)(tag + k + u); ++cnt; }
                 }
-                k += 4u;
             }
-            if (k > hi) k = hi;
-            const bool full = cnt + 4u > FORCE_CAP && k < hi;
+            for (; k < hi && cnt < CAP && !(k + 4u <= hi && cnt + 4u <= CAP); ++k) {
+                const float2 q = src[k];
+                const float ox = q.x - me.x, oyv = q.y - me.y;
+                const float r2 = ox * ox + oyv * oyv;
+                if (k != ii && !(r2 > P.sqr_radius)) { s_list[cnt * FS_BLOCK + tid] = (entry_t)(tag + k); ++cnt; }
+            }
+            const bool full = cnt == CAP && k < hi;
             const bool flush = __any(full) || r > 2;
             if (flush) {
                 // heavy phase: two neighbours per trip (independent divide chains in flight), terms
@@ -363,22 +363,19 @@ __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges
                         const bool two = e + 1u < cnt;
                         const uint32_t j0 = s_list[e * FS_BLOCK + tid];
                         const uint32_t j1 = s_list[(two ? e + 1u : e) * FS_BLOCK + tid];
-                        float2 q0, q1, v0, v1;
-                        float d0, d1;
+                        float2 q0, q1;
+                        uint32_t g0, g1;
                         if (STAGED) {
-                            const uint32_t r0 = j0 >> 16, o0 = j0 & 0xFFFFu, r1 = j1 >> 16, o1 = j1 & 0xFFFFu;
+                            const uint32_t r0 = j0 >> 14, o0 = j0 & 0x3FFFu, r1 = j1 >> 14, o1 = j1 & 0x3FFFu;
                             q0 = s_pred[r0][o0]; q1 = s_pred[r1][o1];
-#if FS_FORCE_STAGE_ALL
-                            v0 = s_vel[r0][o0]; d0 = s_rho[r0][o0]; v1 = s_vel[r1][o1]; d1 = s_rho[r1][o1];
-#else
-                            const uint32_t g0 = (r0 == 0 ? blo[0] : r0 == 1 ? blo[1] : blo[2]) + o0;
-                            const uint32_t g1 = (r1 == 0 ? blo[0] : r1 == 1 ? blo[1] : blo[2]) + o1;
-                            v0 = vel_s[g0]; d0 = rho[g0]; v1 = vel_s[g1]; d1 = rho[g1];
-#endif
+                            g0 = (r0 == 0 ? blo[0] : r0 == 1 ? blo[1] : blo[2]) + o0;
+                            g1 = (r1 == 0 ? blo[0] : r1 == 1 ? blo[1] : blo[2]) + o1;
                         } else {
-                            q0 = pred[j0]; v0 = vel_s[j0]; d0 = rho[j0];
-                            q1 = pred[j1]; v1 = vel_s[j1]; d1 = rho[j1];
+                            g0 = j0; g1 = j1;
+                            q0 = pred[g0]; q1 = pred[g1];
                         }
+                        const float2 v0 = vel_s[g0], v1 = vel_s[g1];
+                        const float d0 = rho[g0], d1 = rho[g1];
                         const ForceTerms T0 = force_terms(P, me, mv, pressure, q0, v0, d0, A.seed);
                         uint32_t seed1 = A.seed;
                         const ForceTerms T1 = force_terms(P, me, mv, pressure, q1, v1, d1, seed1);
@@ -391,7 +388,6 @@ __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges
             if (!__any(k < hi)) break;
         }
     }
-    (void)live;
 }
 
 __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* __restrict__ pos_s,
@@ -401,15 +397,8 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
                                                     const uint32_t* __restrict__ start_ref,
                                                     const u64* __restrict__ pairs, const float2* __restrict__ tex,
                                                     float2* __restrict__ pos_out, float2* __restrict__ vel_out) {
-    __shared__ uint32_t s_list[FORCE_CAP * FS_BLOCK];
+    __shared__ unsigned short s_list[FORCE_CAP * FS_BLOCK];
     __shared__ float2 s_pred[3][NBF_TILE];
-#if FS_FORCE_STAGE_ALL
-    __shared__ float2 s_vel[3][NBF_TILE];
-    __shared__ float s_rho[3][NBF_TILE];
-#else
-    const float2 (*s_vel)[NBF_TILE] = nullptr;
-    const float (*s_rho)[NBF_TILE] = nullptr;
-#endif
     __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * FS_BLOCK + tid;
@@ -448,15 +437,11 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
         for (int r = 0; r < 3; ++r)
             for (uint32_t j = tid; j < bhi[r] - blo[r]; j += FS_BLOCK) {
                 s_pred[r][j] = pred[blo[r] + j];
-#if FS_FORCE_STAGE_ALL
-                s_vel[r][j] = vel_s[blo[r] + j];
-                s_rho[r][j] = rho[blo[r] + j];
-#endif
             }
         __syncthreads();
-        force_sweep<true>(P, R, blo, ii, live, me, mv, pressure, pred, vel_s, rho, s_pred, s_vel, s_rho, s_list, A);
+        force_sweep<true>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho, s_pred, s_list, A);
     } else {
-        force_sweep<false>(P, R, blo, ii, live, me, mv, pressure, pred, vel_s, rho, s_pred, s_vel, s_rho, s_list, A);
+        force_sweep<false>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho, s_pred, s_list, A);
     }
     if (!live) return;
     const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
