@@ -31,8 +31,11 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, out=None, extra_flags=()):
+    """Compile and link.  `out`/`extra_flags` build an experimental variant next to the default library."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if out is not None:
+        return _build_variant(hipcc, out, list(extra_flags), verbose)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
@@ -56,6 +59,15 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return OUT
+
+
+def _build_variant(hipcc, out, extra, verbose):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + extra + ["-shared", "-o", out] + srcs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":

@@ -105,6 +105,7 @@ struct fs_sim {
     DevArray<float> rho;
     DevArray<uint32_t> key;
     DevArray<fsd::u64> pairs;
+    DevArray<uint32_t> sort_dirty;  // per-tile flags of the bitonic sort
     DevArray<uint32_t> cs;          // dense cell-start table, ncell+1
     DevArray<uint32_t> start_ref;   // reference start_indices (persistent, never cleared)
     DevArray<float2> tex;           // force field
@@ -135,7 +136,7 @@ struct fs_sim {
 
     void release() {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release();
-        key.release(); pairs.release(); cs.release(); start_ref.release(); tex.release(); work.release();
+        key.release(); pairs.release(); sort_dirty.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
         owned.release(); flags.release(); blockcnt.release(); blockoff.release(); slab_counters.release();
         hist.release();
@@ -288,7 +289,7 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     fsd::launch_predict_key(st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
     if (prof) FS_HIP(hipEventRecord(ev[1], st));
     if (s->opts.sort_mode == FS_SORT_BITONIC) {
-        fsd::launch_bitonic_sort(st, s->pairs.p, s->n);
+        fsd::launch_bitonic_sort(st, s->pairs.p, s->n, s->sort_dirty.p);
     } else {
         return fail(FS_ERR_UNSUPPORTED, "sort_mode not built");
     }
@@ -367,6 +368,8 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
     FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
+    FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1));
     FS_TRY(s->start_ref.alloc(s->ncell));
     FS_TRY(s->tex.alloc((size_t)settings->texture_size.x * settings->texture_size.y));
@@ -611,6 +614,8 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
     FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
+    FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->owned.alloc(cap)); FS_TRY(s->flags.alloc(cap));
     const size_t nblocks = (cap + 255) / 256;
     FS_TRY(s->blockcnt.alloc(nblocks)); FS_TRY(s->blockoff.alloc(nblocks));
@@ -708,7 +713,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
                             s->slab_cfg.has_right ? recv_right : nullptr, s->pos.p, s->vel.p, s->pairs.p,
                             s->slab_counters.p);
     if (ev) FS_HIP(hipEventRecord(ev[1], st));
-    fsd::launch_bitonic_sort(st, s->pairs.p, s->capacity);
+    fsd::launch_bitonic_sort(st, s->pairs.p, s->capacity, s->sort_dirty.p);
     if (ev) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
                              s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,

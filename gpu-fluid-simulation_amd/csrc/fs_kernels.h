@@ -45,6 +45,8 @@ size_t slab_message_bytes(uint32_t R);
 
 // Bitonic network of sort.wgsl:27-51 / simulation.rs:323-347 on (key<<32 | index) pairs.
 // Returns the number of kernel launches issued.
-int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n);
+// `dirty`: one u32 per 4096-element tile (sort_tile_count(n) entries), scratch owned by the caller.
+int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty);
+uint32_t sort_tile_count(uint32_t n);
 
 }  // namespace fsd

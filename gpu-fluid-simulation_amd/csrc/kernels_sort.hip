@@ -141,12 +141,19 @@ __device__ __forceinline__ void lt_store_l3(u64* __restrict__ pairs, const u64 (
     }
 }
 
+// `dirty[tile]` != 0 when a strided pass of the current stage swapped an element of the tile.
+// A clean tile is still sorted (it was left sorted by the previous stage's tail / the init
+// pass), so every compare of its tail is lower-index <= higher-index: a no-op.  Skipping it
+// is therefore exact, not an approximation.
 template <bool INIT>
 __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict__ pairs, uint32_t n,
-                                                                uint32_t num_stages) {
+                                                                uint32_t num_stages, uint32_t* __restrict__ dirty) {
     __shared__ u64 s[LT_LDS_ELEMS];
     const uint32_t base = blockIdx.x * SORT_T;
     const uint32_t t = threadIdx.x;
+    if (!INIT) {
+        if (dirty[blockIdx.x] == 0) return;            // uniform: whole tile provably unchanged
+    }
     u64 x[LT_E];
     if (INIT) {
         // coalesced load, straight into LDS, then the L3 view
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
         lt_round<3, false>(x);
     }
     lt_store_l3(pairs, x, base, t, n);
+    if (t == 0) dirty[blockIdx.x] = 0;                 // sorted again
 }
 
 // M consecutive global steps of one stage in ONE pass, register-blocked: a thread owns the
@@ -200,15 +208,55 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
 // from p = v ^ (2^a - 1)) the mirror step is a plain distance-2^a step; the later steps of
 // the pass act on upper-half rows in reversed physical order, so the compare is reversed
 // there.  Indices >= n hold a never-moving sentinel (see file header).
+//
+// Exact skipping (try_skip): a workgroup covers 256 consecutive columns of its 2^M rows; each
+// row's 256-element chunk lies in one tile.  If all those tiles are clean (sorted) a chunk's
+// keys are bounded by its first and last element, and if the chunks are ordered
+// last(chunk) <= first(next chunk) in PHYSICAL index order then every compare-exchange of
+// the pass has key[lower index] <= key[higher index]: no swap can happen and the workgroup
+// returns after reading 2 elements per row instead of the whole 2^M x 256 block.
 template <int M, bool FLIP>
 __global__ __launch_bounds__(256) void k_bitonic_strided(u64* __restrict__ pairs, uint32_t n, uint32_t a,
-                                                         uint32_t num_threads) {
+                                                         uint32_t num_threads, uint32_t* __restrict__ dirty,
+                                                         int try_skip) {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= num_threads) return;
     constexpr int R = 1 << M;
     const uint32_t low = a - (uint32_t)M + 1u;
-    const uint32_t vbase = ((g >> low) << (a + 1u)) | (g & ((1u << low) - 1u));
     const uint32_t mirror = (1u << a) - 1u;
+    if (try_skip) {                                    // uniform branch (kernel argument)
+        __shared__ uint32_t s_first[R], s_last[R];
+        __shared__ int s_skip;
+        const uint32_t l = threadIdx.x;
+        if (l < (uint32_t)R) {
+            // row l in PHYSICAL order: lower half as is; with FLIP the upper half is mirrored, so its
+            // rows appear in reverse order and each chunk is read back to front
+            const bool upper = FLIP && (l >> (M - 1));
+            const uint32_t rv = upper ? (uint32_t)(R - 1) - (l - (uint32_t)(R / 2)) : l;   // virtual row
+            const uint32_t g0 = blockIdx.x * 256u, g1 = g0 + 255u;
+            const uint32_t v0 = (((g0 >> low) << (a + 1u)) | (g0 & ((1u << low) - 1u))) | (rv << low);
+            const uint32_t v1 = (((g1 >> low) << (a + 1u)) | (g1 & ((1u << low) - 1u))) | (rv << low);
+            const uint32_t pf = upper ? (v1 ^ mirror) : v0;      // physically first / last element of the chunk
+            const uint32_t pl = upper ? (v0 ^ mirror) : v1;
+            const bool clean = dirty[pf >> SORT_LOG_T] == 0;
+            const uint32_t kf = pf < n ? (uint32_t)(pairs[pf] >> 32) : 0xFFFFFFFFu;
+            const uint32_t kl = pl < n ? (uint32_t)(pairs[pl] >> 32) : 0xFFFFFFFFu;
+            s_first[l] = clean ? kf : 0u;               // a dirty row can never certify:
+            s_last[l] = clean ? kl : 0xFFFFFFFFu;       //   its "range" is everything
+        }
+        __syncthreads();
+        if (l == 0) {
+            int ok = 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) ok &= (s_first[r] <= s_last[r]);   // dirty rows fail here? no: checked below
+#pragma unroll
+            for (int r = 0; r + 1 < R; ++r) ok &= (s_last[r] <= s_first[r + 1]);
+            s_skip = ok;
+        }
+        __syncthreads();
+        if (s_skip) return;
+    }
+    if (g >= num_threads) return;
+    const uint32_t vbase = ((g >> low) << (a + 1u)) | (g & ((1u << low) - 1u));
     u64 x[R];
     u64 changed = 0;   // bit r set when x[r] took part in a swap: untouched elements are not stored
 #pragma unroll
@@ -237,16 +285,21 @@ __global__ __launch_bounds__(256) void k_bitonic_strided(u64* __restrict__ pairs
     for (int r = 0; r < R; ++r) {
         const uint32_t v = vbase | ((uint32_t)r << low);
         const uint32_t p = (FLIP && (r >> (M - 1))) ? (v ^ mirror) : v;
-        if ((changed >> r) & 1ull) pairs[p] = x[r];   // a sentinel (p >= n) never swaps, so p < n here
+        if ((changed >> r) & 1ull) {                 // a sentinel (p >= n) never swaps, so p < n here
+            pairs[p] = x[r];
+            dirty[p >> SORT_LOG_T] = 1u;              // this tile's tail must run
+        }
     }
 }
 
 template <int M>
-static void launch_strided(hipStream_t st, u64* pairs, uint32_t n, uint32_t a, bool flip, uint32_t p2) {
+static void launch_strided(hipStream_t st, u64* pairs, uint32_t n, uint32_t a, bool flip, uint32_t p2,
+                           uint32_t* dirty, int try_skip) {
     const uint32_t threads = p2 >> M;
     const dim3 grid((threads + 255u) / 256u), block(256);
-    if (flip) hipLaunchKernelGGL((k_bitonic_strided<M, true>), grid, block, 0, st, pairs, n, a, threads);
-    else hipLaunchKernelGGL((k_bitonic_strided<M, false>), grid, block, 0, st, pairs, n, a, threads);
+    if (threads < 256u) try_skip = 0;                  // the certificate assumes full 256-column workgroups
+    if (flip) hipLaunchKernelGGL((k_bitonic_strided<M, true>), grid, block, 0, st, pairs, n, a, threads, dirty, try_skip);
+    else hipLaunchKernelGGL((k_bitonic_strided<M, false>), grid, block, 0, st, pairs, n, a, threads, dirty, try_skip);
 }
 
 static int sort_mmax() {
@@ -258,15 +311,21 @@ static int sort_mmax() {
     return m;
 }
 
-int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n) {
+static int sort_skip_stage() {
+    static int m = [] { const char* e = getenv("FS_SORT_SKIP_STAGE"); return e ? atoi(e) : 12; }();
+    return m;   // first stage whose strided passes try the no-op certificate (<0: never)
+}
+
+int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty) {
     if (n <= 1) return 0;
     uint32_t p2 = 1, S = 0;
     while (p2 < n) { p2 <<= 1; ++S; }
     const uint32_t tiles = (n + SORT_T - 1) / SORT_T;
     int launches = 0;
     const uint32_t init_stages = S < SORT_LOG_T ? S : SORT_LOG_T;
-    hipLaunchKernelGGL(k_bitonic_local<true>, dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, init_stages);
-    ++launches;
+    hipLaunchKernelGGL(k_bitonic_local<true>, dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, init_stages, dirty);
+    ++launches;                                         // leaves every tile sorted and its flag cleared
+    const int skip_from = sort_skip_stage();
     const int mmax = sort_mmax();
     for (uint32_t stage = SORT_LOG_T; stage < S; ++stage) {
         // steps whose block (2 << sh) exceeds the tile: sh = stage .. SORT_LOG_T, in passes of <= mmax steps
@@ -276,21 +335,28 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n) {
         for (int ps = 0; ps < npass; ++ps) {
             const int m = gsteps / npass + (ps < gsteps % npass ? 1 : 0);
             const bool flip = ps == 0;
+            const int ts = (skip_from >= 0 && (int)stage >= skip_from) ? 1 : 0;
             switch (m) {
-                case 1: launch_strided<1>(st, pairs, n, a, flip, p2); break;
-                case 2: launch_strided<2>(st, pairs, n, a, flip, p2); break;
-                case 3: launch_strided<3>(st, pairs, n, a, flip, p2); break;
-                case 4: launch_strided<4>(st, pairs, n, a, flip, p2); break;
-                case 5: launch_strided<5>(st, pairs, n, a, flip, p2); break;
-                default: launch_strided<6>(st, pairs, n, a, flip, p2); break;
+                case 1: launch_strided<1>(st, pairs, n, a, flip, p2, dirty, ts); break;
+                case 2: launch_strided<2>(st, pairs, n, a, flip, p2, dirty, ts); break;
+                case 3: launch_strided<3>(st, pairs, n, a, flip, p2, dirty, ts); break;
+                case 4: launch_strided<4>(st, pairs, n, a, flip, p2, dirty, ts); break;
+                case 5: launch_strided<5>(st, pairs, n, a, flip, p2, dirty, ts); break;
+                default: launch_strided<6>(st, pairs, n, a, flip, p2, dirty, ts); break;
             }
             a -= (uint32_t)m;
             ++launches;
         }
-        hipLaunchKernelGGL(k_bitonic_local<false>, dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, 0u);
+        hipLaunchKernelGGL(k_bitonic_local<false>, dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, 0u, dirty);
         ++launches;
     }
     return launches;
+}
+
+uint32_t sort_tile_count(uint32_t n) {
+    uint32_t p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    return (p2 + SORT_T - 1) / SORT_T + 1u;   // tiles of the padded array (sentinel tiles included)
 }
 
 }  // namespace fsd

@@ -265,7 +265,10 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
 //   heavy — pressure + viscosity terms for the listed neighbours, accumulated in list order,
 //           which is the reference visiting order, so sums keep their association.
 // A full list (FORCE_CAP) is flushed wave-uniformly and scanning resumes.
-#define FORCE_CAP 24          // neighbour-list entries per lane (u16 when staged, u32 entries = CAP/2 otherwise)
+#ifndef FORCE_CAP
+#define FORCE_CAP 16            // measured on MI355X @16M: 8: 1.12 ms, 12: 1.18, 16: 1.04, 20: 1.06, 24: 1.11, 32: 1.17
+#endif
+// neighbour-list entries per lane (u16 when staged, u32 entries = CAP/2 otherwise)
 
 struct ForceAcc { float fpx, fpy, fvx, fvy; uint32_t seed; };
 struct ForceTerms { float px, py, vx, vy; };
@@ -310,7 +313,10 @@ __device__ __forceinline__ ForceTerms force_terms(const StepParams& P, const flo
     return T;
 }
 
-#define NBF_TILE 448         // staged candidates (predicted positions) per sweep row in k_force; vel/rho of the
+#ifndef NBF_TILE
+#define NBF_TILE 384
+#endif
+// staged candidates (predicted positions) per sweep row in k_force; vel/rho of the
                              // few in-radius neighbours are gathered in the heavy phase (staging them too cost
                              // occupancy and measured slower: the kernel is issue-bound, not latency-bound)
 

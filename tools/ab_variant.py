@@ -1,0 +1,15 @@
+import sys, os, json
+sys.path.insert(0, os.getcwd())
+import gpu_fluid_simulation_amd as g
+from gpu_fluid_simulation_amd import _abi
+variant = sys.argv[1]
+if variant != "default":
+    _abi._lib = _abi.load_library(os.path.join("gpu-fluid-simulation_amd", variant))
+n = 1 << 24
+st, off, tick = g.dam_break_2d(n)
+sim = g.FluidSimulation(st, device=0, initial_offset=off)
+for _ in range(5): sim.tick(tick)
+sim.sync(); sim.profile(True); sim.profile_read(True)
+ms = sim.timed_steps(tick, 20)
+p, k = sim.profile_read(True)
+print(variant, round(ms/20, 4), {a: round(b/20, 4) for a, b in p.items()})
