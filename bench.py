@@ -57,7 +57,7 @@ def cpu_baseline(seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)   # >= 10 warm-up + >= 100 timed steps
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="dam_break_2d_16M", choices=sorted(WORKLOADS))
     ap.add_argument("--sort", default="bitonic", choices=["bitonic", "counting"])
