@@ -18,18 +18,22 @@ from . import _abi
 from ._abi import (  # noqa: F401
     FS_SORT_BITONIC,
     FS_SORT_COUNTING,
+    PARTICLE3_DTYPE,
     PARTICLE_DTYPE,
     PASS_NAMES,
     ExtensionMissing,
     Options,
     Settings,
+    Settings3,
     SlabConfig,
     SlabCounters,
     SortStep,
     TickSettings,
+    TickSettings3,
     Uniform,
     UVec2,
     Vec2,
+    Vec3,
     load_library,
 )
 
@@ -198,6 +202,96 @@ class FluidSimulation:
         p, n = C.c_void_p(), C.c_size_t()
         _check(self._lib, self._lib.fs_start_indices_device(self._h, C.byref(p), C.byref(n)))
         return p.value, int(n.value)
+
+
+def dam_break_3d(n):
+    """3D benchmark scene (SURVEY.md §8d `dam_break_3d`; build-defined, no reference counterpart):
+    side^3 cube lattice, s = 0.1, h = 0.2, box (2L, 1.25L, L + 2s), block one spacing off the -x wall
+    and the +y floor, centred in z; reference tick defaults with gravity (0, 9.81, 0)."""
+    f = np.float32
+    side = int(round(n ** (1.0 / 3.0)))
+    if side ** 3 != n:
+        raise ValueError("dam_break_3d expects a cube particle count")
+    s, h = f(0.1), f(0.2)
+    L = f(side) * s
+    size = (f(2.0) * L, f(1.25) * L, L + f(2.0) * s)
+    off = (-size[0] / f(2) + L / f(2) + s / f(2), size[1] / f(2) - L / f(2) - s / f(2), f(0.0))
+    st = Settings3(int(n), float(s), float(h), Vec3(float(size[0]), float(size[1]), float(size[2])))
+    tick = TickSettings3(float(f(1.0) / f(120.0)), Vec3(0.0, 9.81, 0.0), 1.0, 50.0, 0.0, 0.1, 25.0)
+    return st, (float(off[0]), float(off[1]), float(off[2])), tick
+
+
+class FluidSimulation3D:
+    """3D extension (include/fluidsim.h fs3_*); not in the reference."""
+
+    def __init__(self, settings, device=0, initial_offset=(0.0, 0.0, 0.0)):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.settings = settings
+        off = Vec3(*[float(x) for x in initial_offset])
+        _check(self._lib, self._lib.fs3_create(C.byref(settings), int(device), off, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.fs3_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tick(self, t):
+        _check(self._lib, self._lib.fs3_step(self._h, C.byref(t)))
+
+    def sync(self):
+        _check(self._lib, self._lib.fs3_sync(self._h))
+
+    @property
+    def tick_count(self):
+        return int(self._lib.fs3_tick_count(self._h))
+
+    @property
+    def particle_count(self):
+        return int(self._lib.fs3_particle_count(self._h))
+
+    @property
+    def grid_dims(self):
+        w, h, d = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(self._lib, self._lib.fs3_grid_dims(self._h, C.byref(w), C.byref(h), C.byref(d)))
+        return int(w.value), int(h.value), int(d.value)
+
+    def download_particles(self):
+        out = np.empty(self.particle_count, dtype=PARTICLE3_DTYPE)
+        _check(self._lib, self._lib.fs3_download_particles(self._h, out.ctypes.data_as(C.c_void_p), out.shape[0]))
+        return out
+
+    def upload_particles(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=PARTICLE3_DTYPE)
+        _check(self._lib, self._lib.fs3_upload_particles(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0]))
+
+    def timed_steps(self, t, steps):
+        ms = C.c_double()
+        _check(self._lib, self._lib.fs3_timed_steps(self._h, C.byref(t), int(steps), C.byref(ms)))
+        return float(ms.value)
+
+    def profile(self, enable=True):
+        _check(self._lib, self._lib.fs3_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * len(PASS_NAMES))()
+        steps = C.c_uint64()
+        _check(self._lib, self._lib.fs3_profile_read(self._h, ms, C.byref(steps), 1 if reset else 0))
+        return dict(zip(PASS_NAMES, [float(x) for x in ms])), int(steps.value)
+
+
+def reference_lattice_3d(settings, offset=(0.0, 0.0, 0.0)):
+    lib = load_library()
+    out = np.zeros(settings.particle_count, dtype=PARTICLE3_DTYPE)
+    _check(lib, lib.fs3_reference_lattice(C.byref(settings), Vec3(*[float(x) for x in offset]),
+                                          out.ctypes.data_as(C.c_void_p), out.shape[0]))
+    return out
 
 
 class SlabSimulation:

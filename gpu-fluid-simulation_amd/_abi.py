@@ -101,6 +101,25 @@ class Options(C.Structure):
     ]
 
 
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Settings3(C.Structure):
+    _fields_ = [("particle_count", C.c_uint32), ("particle_spacing", C.c_float), ("smoothing_radius", C.c_float),
+                ("size", Vec3)]
+
+
+class TickSettings3(C.Structure):
+    _fields_ = [("delta", C.c_float), ("gravity", Vec3), ("mass", C.c_float), ("pressure_constant", C.c_float),
+                ("rest_density", C.c_float), ("damping_factor", C.c_float), ("viscosity_coefficient", C.c_float)]
+
+
+PARTICLE3_DTYPE = np.dtype([("position", "<f4", (3,)), ("predicted_position", "<f4", (3,)), ("velocity", "<f4", (3,)),
+                            ("density", "<f4"), ("grid", "<u4"), ("pad", "<u4")])
+assert PARTICLE3_DTYPE.itemsize == 48
+
+
 class SlabConfig(C.Structure):
     _fields_ = [
         ("own_lo", C.c_uint32), ("own_hi", C.c_uint32),
@@ -177,6 +196,19 @@ PROTOTYPES = {
     "fs_slab_counters_read": (C.c_int, [_P, C.POINTER(SlabCounters)]),
     "fs_slab_download": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     "fs_slab_column_histogram": (C.c_int, [_P, _P, C.c_size_t]),
+    "fs3_create": (C.c_int, [C.POINTER(Settings3), C.c_int, Vec3, C.POINTER(_P)]),
+    "fs3_destroy": (None, [_P]),
+    "fs3_step": (C.c_int, [_P, C.POINTER(TickSettings3)]),
+    "fs3_sync": (C.c_int, [_P]),
+    "fs3_tick_count": (C.c_uint32, [_P]),
+    "fs3_particle_count": (C.c_uint32, [_P]),
+    "fs3_grid_dims": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "fs3_download_particles": (C.c_int, [_P, _P, C.c_size_t]),
+    "fs3_upload_particles": (C.c_int, [_P, _P, C.c_size_t]),
+    "fs3_reference_lattice": (C.c_int, [C.POINTER(Settings3), Vec3, _P, C.c_size_t]),
+    "fs3_timed_steps": (C.c_int, [_P, C.POINTER(TickSettings3), C.c_uint32, C.POINTER(C.c_double)]),
+    "fs3_profile_enable": (C.c_int, [_P, C.c_int]),
+    "fs3_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "fs_buffer_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_char_p, C.POINTER(_P)]),
     "fs_buffer_resize": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_int)]),
     "fs_buffer_write": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),

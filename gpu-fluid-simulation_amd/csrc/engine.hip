@@ -33,6 +33,9 @@ fs_status fail(fs_status st, const std::string& msg) {
     g_err = msg;
     return st;
 }
+}  // namespace
+namespace fsd { void set_last_error(const std::string& msg) { g_err = msg; } }   // used by sim3d.hip
+namespace {
 
 #define FS_HIP(expr)                                                                                     \
     do {                                                                                                 \

@@ -159,23 +159,6 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_unpack(StepParams P, uint32_t
     pairs[slot] = ((u64)key << 32) | (u64)slot;
 }
 
-struct GapEntry { uint32_t begin, end, value; };
-#define FS_GAP_INLINE 16u
-#define FS_GAP_CHUNK 16384u
-
-__device__ __forceinline__ void fill_cells_slab(uint32_t* __restrict__ cs, uint32_t begin, uint32_t end,
-                                                uint32_t value, GapEntry* __restrict__ work,
-                                                uint32_t* __restrict__ counter, uint32_t work_cap) {
-    if (end <= begin) return;
-    if (end - begin <= FS_GAP_INLINE) { for (uint32_t c = begin; c < end; ++c) cs[c] = value; return; }
-    for (uint32_t b = begin; b < end; b += FS_GAP_CHUNK) {
-        const uint32_t e = (end - b > FS_GAP_CHUNK) ? b + FS_GAP_CHUNK : end;
-        const uint32_t slot = atomicAdd(counter, 1u);
-        if (slot < work_cap) work[slot] = GapEntry{b, e, value};
-        else for (uint32_t c = b; c < e; ++c) cs[c] = value;
-    }
-}
-
 // k_reorder for slab mode: DEAD slots are skipped, the live count and the owned flags are
 // produced here.  `cap` = number of slots sorted.
 __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_t cap, const u64* __restrict__ pairs,
@@ -193,7 +176,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
     const uint32_t key = (uint32_t)(pr >> 32);
     const uint32_t prev = i ? (uint32_t)(pairs[i - 1] >> 32) : 0u;
     if (key == FS_DEAD_KEY) {
-        if (i == 0) { *n_live_out = 0; fill_cells_slab(cs, 0u, P.ncell + 1u, 0u, work, counter, work_cap); }
+        if (i == 0) { *n_live_out = 0; fill_cells(cs, 0u, P.ncell + 1u, 0u, work, counter, work_cap); }
         else if (prev != FS_DEAD_KEY) *n_live_out = i;
         owned[i] = 0;
         return;
@@ -212,15 +195,15 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
     const uint32_t kc = key < P.ncell ? key : P.ncell;
     if (i == 0) {
         if (key < P.ncell) start_ref[key] = 0;
-        fill_cells_slab(cs, 0u, kc + 1u, 0u, work, counter, work_cap);
+        fill_cells(cs, 0u, kc + 1u, 0u, work, counter, work_cap);
     } else if (key != prev) {
         if (key < P.ncell) start_ref[key] = i;
         const uint32_t pc = prev < P.ncell ? prev : P.ncell;
-        fill_cells_slab(cs, pc + 1u, kc + 1u, i, work, counter, work_cap);
+        fill_cells(cs, pc + 1u, kc + 1u, i, work, counter, work_cap);
     }
     const bool last = (i + 1 == cap) || ((uint32_t)(pairs[i + 1] >> 32) == FS_DEAD_KEY);
     if (last) {
-        fill_cells_slab(cs, kc + 1u, P.ncell + 1u, i + 1u, work, counter, work_cap);
+        fill_cells(cs, kc + 1u, P.ncell + 1u, i + 1u, work, counter, work_cap);
         if (i + 1 == cap) *n_live_out = cap;
     }
 }

@@ -31,30 +31,6 @@ __global__ __launch_bounds__(FS_BLOCK) void k_predict_key(StepParams P, const fl
 // --------------------------------------------------- dense cell-start table fill
 // cs[c] = index of the first sorted particle whose key is >= c (c in [0, ncell]).
 // Short gaps are written by the boundary lane; long gaps go to a worklist.
-#define FS_GAP_INLINE 16u
-#define FS_GAP_CHUNK 16384u
-
-struct GapEntry { uint32_t begin, end, value; };
-
-__device__ __forceinline__ void fill_cells(uint32_t* __restrict__ cs, uint32_t begin, uint32_t end, uint32_t value,
-                                           GapEntry* __restrict__ work, uint32_t* __restrict__ counter,
-                                           uint32_t work_cap) {
-    if (end <= begin) return;
-    if (end - begin <= FS_GAP_INLINE) {
-        for (uint32_t c = begin; c < end; ++c) cs[c] = value;
-        return;
-    }
-    for (uint32_t b = begin; b < end; b += FS_GAP_CHUNK) {
-        const uint32_t e = (end - b > FS_GAP_CHUNK) ? b + FS_GAP_CHUNK : end;
-        const uint32_t slot = atomicAdd(counter, 1u);
-        if (slot < work_cap) {
-            work[slot] = GapEntry{b, e, value};
-        } else {
-            for (uint32_t c = b; c < e; ++c) cs[c] = value;   // never expected: capacity covers the worst case
-        }
-    }
-}
-
 __global__ __launch_bounds__(FS_BLOCK) void k_fill_gaps(uint32_t* __restrict__ cs, const GapEntry* __restrict__ work,
                                                         const uint32_t* __restrict__ counter, uint32_t work_cap) {
     uint32_t count = *counter;

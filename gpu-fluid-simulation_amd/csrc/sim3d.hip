@@ -1,0 +1,502 @@
+// sim3d.hip — 3D extension of the step (27-cell neighbour path).  NOT in the reference (2D
+// only); build-defined per SURVEY.md Appendix B.3, normative statement oracle/sph_oracle3d.cpp.
+// Same pass chain as 2D: predict+key -> bitonic (key,index) sort -> reorder + dense cell
+// starts -> density -> force+integrate.  SoA with 16-byte lanes: pos4 / vel4 / pred4 (xyz,
+// pred.w carries the density for the force pass), so a neighbour is two 16-B loads.
+// A row of the 27-cell sweep (fixed z,y; x-1..x+1) is ONE contiguous index range, visited
+// z outer, y, x inner, index ascending = the oracle's order, so sums are bit-identical.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fluidsim.h"
+#include "fs_kernels.h"
+
+static_assert(sizeof(fs3_particle) == 48, "fs3_particle is 48 bytes");
+
+namespace fsd {
+
+void set_last_error(const std::string& msg);   // engine.hip
+
+struct Params3 {
+    uint32_t n, gw, gh, gd, ncell;
+    float dt, h, h2;
+    float bx, by, bz;            // bounds * 0.5
+    float mass, poly6, pressure_k, rest_density, damping, visc_coeff, spiky, visc_k;
+    float gx, gy, gz;
+    uint32_t frame;
+};
+
+#define B3 256
+#define CAP3 16
+
+__device__ __forceinline__ float4 predict3(const Params3& P, float4 p, float4 v) {
+    float4 r;
+    r.x = p.x + v.x * P.dt; r.y = p.y + v.y * P.dt; r.z = p.z + v.z * P.dt; r.w = 0.0f;
+    if (fabsf(r.x) > P.bx) r.x = P.bx * sign_f32(r.x);
+    if (fabsf(r.y) > P.by) r.y = P.by * sign_f32(r.y);
+    if (fabsf(r.z) > P.bz) r.z = P.bz * sign_f32(r.z);
+    return r;
+}
+__device__ __forceinline__ void cell3(const Params3& P, float4 pt, uint32_t* cx, uint32_t* cy, uint32_t* cz) {
+    *cx = f32_to_u32_sat(floorf(__fdiv_rn(pt.x + P.bx, P.h))) + 1u;
+    *cy = f32_to_u32_sat(floorf(__fdiv_rn(pt.y + P.by, P.h))) + 1u;
+    *cz = f32_to_u32_sat(floorf(__fdiv_rn(pt.z + P.bz, P.h))) + 1u;
+}
+
+__global__ __launch_bounds__(B3) void k3_predict_key(Params3 P, const float4* __restrict__ pos,
+                                                     const float4* __restrict__ vel, u64* __restrict__ pairs,
+                                                     uint32_t* __restrict__ gap_counter) {
+    const uint32_t i = blockIdx.x * B3 + threadIdx.x;
+    if (i == 0) *gap_counter = 0;
+    if (i >= P.n) return;
+    uint32_t cx, cy, cz;
+    cell3(P, predict3(P, pos[i], vel[i]), &cx, &cy, &cz);
+    pairs[i] = ((u64)((cz * P.gh + cy) * P.gw + cx) << 32) | (u64)i;
+}
+
+__global__ __launch_bounds__(B3) void k3_reorder(Params3 P, const u64* __restrict__ pairs,
+                                                 const float4* __restrict__ pos_in, const float4* __restrict__ vel_in,
+                                                 float4* __restrict__ pos_s, float4* __restrict__ vel_s,
+                                                 float4* __restrict__ pred, uint32_t* __restrict__ key_s,
+                                                 uint32_t* __restrict__ cs, GapEntry* __restrict__ work,
+                                                 uint32_t* __restrict__ counter, uint32_t work_cap) {
+    const uint32_t i = blockIdx.x * B3 + threadIdx.x;
+    if (i >= P.n) return;
+    const u64 pr = pairs[i];
+    const uint32_t key = (uint32_t)(pr >> 32), src = (uint32_t)pr;
+    const float4 p = pos_in[src], v = vel_in[src];
+    pos_s[i] = p; vel_s[i] = v; pred[i] = predict3(P, p, v); key_s[i] = key;
+    const uint32_t kc = key < P.ncell ? key : P.ncell;
+    if (i == 0) {
+        fill_cells(cs, 0u, kc + 1u, 0u, work, counter, work_cap);
+    } else {
+        const uint32_t prev = (uint32_t)(pairs[i - 1] >> 32);
+        if (key != prev) fill_cells(cs, (prev < P.ncell ? prev : P.ncell) + 1u, kc + 1u, i, work, counter, work_cap);
+    }
+    if (i == P.n - 1) fill_cells(cs, kc + 1u, P.ncell + 1u, P.n, work, counter, work_cap);
+}
+
+// row j in 0..8 -> (oz, oy) = (j/3 - 1, j%3 - 1); false when the row is outside the grid
+__device__ __forceinline__ bool row3(const Params3& P, const uint32_t* __restrict__ cs, uint32_t cx, uint32_t cy,
+                                     uint32_t cz, int j, uint32_t* lo, uint32_t* hi) {
+    const uint32_t y = cy + (uint32_t)(j % 3 - 1), z = cz + (uint32_t)(j / 3 - 1);
+    if (y >= P.gh || z >= P.gd) return false;
+    const uint32_t xlo = cx - 1u;                         // cx >= 1 always
+    uint32_t xhi = cx + 2u;                               // exclusive; cells past the row end do not exist
+    if (xhi > P.gw) xhi = P.gw;
+    const uint32_t base = (z * P.gh + y) * P.gw;
+    *lo = cs[base + xlo];
+    *hi = cs[base + xhi];
+    return *lo < *hi;
+}
+
+__device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
+    const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
+    const float r2 = dx * dx + dy * dy + dz * dz;
+    float kern = 0.0f;
+    if (!(r2 > P.h2)) { const float d = P.h2 - r2; kern = P.poly6 * d * d * d; }
+    return P.mass * kern * 1.0f;
+}
+
+__global__ __launch_bounds__(B3) void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs) {
+    const uint32_t i = blockIdx.x * B3 + threadIdx.x;
+    if (i >= P.n) return;
+    const float4 me = pred[i];
+    uint32_t cx, cy, cz;
+    cell3(P, me, &cx, &cy, &cz);
+    float rho = 0.0f;
+#pragma unroll 1
+    for (int j = 0; j < 9; ++j) {
+        uint32_t lo, hi;
+        if (!row3(P, cs, cx, cy, cz, j, &lo, &hi)) continue;
+        uint32_t k = lo;
+        for (; k + 4u <= hi; k += 4u) {
+            const float t0 = dens3(P, me, pred[k]), t1 = dens3(P, me, pred[k + 1u]);
+            const float t2 = dens3(P, me, pred[k + 2u]), t3 = dens3(P, me, pred[k + 3u]);
+            rho += t0; rho += t1; rho += t2; rho += t3;
+        }
+        for (; k < hi; ++k) rho += dens3(P, me, pred[k]);
+    }
+    rho = fmaxf(rho, 1.19209290e-07f);
+    reinterpret_cast<float*>(pred + i)[3] = fmaxf(rho, 0.1f);      // pred.w <- density (other lanes read .xyz only)
+}
+
+struct Acc3 { float px, py, pz, vx, vy, vz; uint32_t seed; };
+struct Terms3 { float px, py, pz, vx, vy, vz; };
+
+__device__ __forceinline__ Terms3 terms3(const Params3& P, float4 me, float4 mv, float pressure, float4 q, float4 nv,
+                                         uint32_t& seed) {
+    const float h = P.h;
+    const float ox = q.x - me.x, oy = q.y - me.y, oz = q.z - me.z;
+    const float r2 = ox * ox + oy * oy + oz * oz;
+    const float dst = sqrt_rn(r2);
+    float dx, dy, dz;
+    if (dst == 0.0f) {
+        const float rx = rand_f32(&seed), ry = rand_f32(&seed), rz = rand_f32(&seed);
+        const float len = sqrt_rn(rx * rx + ry * ry + rz * rz);
+        dx = __fdiv_rn(rx, len); dy = __fdiv_rn(ry, len); dz = __fdiv_rn(rz, len);
+    } else {
+        dx = __fdiv_rn(ox, dst); dy = __fdiv_rn(oy, dst); dz = __fdiv_rn(oz, dst);
+    }
+    const float nrho = q.w;
+    const float npress = P.pressure_k * (nrho - P.rest_density);
+    const float kern = (dst <= h) ? (-(h - dst)) * P.spiky : 0.0f;
+    const float shared = (pressure + npress) * 0.5f;
+    float kv = 0.0f;
+    if (dst <= h)
+        kv = (dst == 0.0f) ? P.visc_k
+                           : P.visc_k * ((__fdiv_rn(-(dst * dst * dst), 2.0f * h * h * h)) + (__fdiv_rn(dst * dst, h * h)) +
+                                         (__fdiv_rn(h, 2.0f * dst)) - 1.0f);
+    Terms3 T;
+    T.px = __fdiv_rn(dx * kern * shared, nrho);
+    T.py = __fdiv_rn(dy * kern * shared, nrho);
+    T.pz = __fdiv_rn(dz * kern * shared, nrho);
+    T.vx = __fdiv_rn(nv.x - mv.x, nrho) * kv;
+    T.vy = __fdiv_rn(nv.y - mv.y, nrho) * kv;
+    T.vz = __fdiv_rn(nv.z - mv.z, nrho) * kv;
+    return T;
+}
+
+// Same two-phase structure as the 2D k_force: scan -> per-lane list in LDS -> dense heavy phase.
+__global__ __launch_bounds__(B3) void k3_force(Params3 P, const float4* __restrict__ pos_s,
+                                               const float4* __restrict__ vel_s, const float4* __restrict__ pred,
+                                               const uint32_t* __restrict__ cs, float4* __restrict__ pos_out,
+                                               float4* __restrict__ vel_out) {
+    __shared__ uint32_t s_list[CAP3 * B3];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * B3 + tid;
+    const bool live = i < P.n;
+    const uint32_t ii = live ? i : P.n - 1;
+    const float4 me = pred[ii];
+    const float4 mv = vel_s[ii];
+    const float mrho = me.w;
+    const float pressure = P.pressure_k * (mrho - P.rest_density);
+    Acc3 A;
+    A.px = A.py = A.pz = A.vx = A.vy = A.vz = 0.0f;
+    A.seed = ii * 12u + P.frame * 69u;
+    uint32_t cx, cy, cz;
+    cell3(P, me, &cx, &cy, &cz);
+    uint32_t cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j <= 9; ++j) {
+        uint32_t lo = 0, hi = 0;
+        if (live && j < 9) { if (!row3(P, cs, cx, cy, cz, j, &lo, &hi)) { lo = 0; hi = 0; } }
+        uint32_t k = lo;
+        for (;;) {
+            for (; k < hi && cnt < CAP3; ++k) {
+                const float4 q = pred[k];
+                const float ox = q.x - me.x, oy = q.y - me.y, oz = q.z - me.z;
+                const float r2 = ox * ox + oy * oy + oz * oz;
+                if (k != ii && !(r2 > P.h2)) { s_list[cnt * B3 + tid] = k; ++cnt; }
+            }
+            const bool full = cnt == CAP3 && k < hi;
+            if (__any(full) || j == 9) {
+                for (uint32_t e = 0; __any(e < cnt); e += 2u) {
+                    if (e < cnt) {
+                        const bool two = e + 1u < cnt;
+                        const uint32_t j0 = s_list[e * B3 + tid], j1 = s_list[(two ? e + 1u : e) * B3 + tid];
+                        const float4 q0 = pred[j0], q1 = pred[j1], v0 = vel_s[j0], v1 = vel_s[j1];
+                        const Terms3 T0 = terms3(P, me, mv, pressure, q0, v0, A.seed);
+                        uint32_t seed1 = A.seed;
+                        const Terms3 T1 = terms3(P, me, mv, pressure, q1, v1, seed1);
+                        A.px += T0.px; A.py += T0.py; A.pz += T0.pz; A.vx += T0.vx; A.vy += T0.vy; A.vz += T0.vz;
+                        if (two) {
+                            A.px += T1.px; A.py += T1.py; A.pz += T1.pz; A.vx += T1.vx; A.vy += T1.vy; A.vz += T1.vz;
+                            A.seed = seed1;
+                        }
+                    }
+                }
+                cnt = 0;
+            }
+            if (!__any(k < hi)) break;
+        }
+    }
+    if (!live) return;
+    float4 v = mv, p = pos_s[i];
+    const float ax = A.px + A.vx * P.visc_coeff, ay = A.py + A.vy * P.visc_coeff, az = A.pz + A.vz * P.visc_coeff;
+    v.x += __fdiv_rn(ax, mrho) * P.dt; v.y += __fdiv_rn(ay, mrho) * P.dt; v.z += __fdiv_rn(az, mrho) * P.dt;
+    v.x += P.gx * P.dt; v.y += P.gy * P.dt; v.z += P.gz * P.dt;
+    if (!(v.x == v.x && v.y == v.y && v.z == v.z)) { v.x = 0.0f; v.y = 0.0f; v.z = 0.0f; }
+    const float speed = sqrt_rn(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (speed > 500.0f) {
+        v.x = __fdiv_rn(v.x, speed) * 500.0f; v.y = __fdiv_rn(v.y, speed) * 500.0f; v.z = __fdiv_rn(v.z, speed) * 500.0f;
+    }
+    p.x += v.x * P.dt; p.y += v.y * P.dt; p.z += v.z * P.dt;
+    if (fabsf(p.x) > P.bx) { p.x = P.bx * sign_f32(p.x); v.x *= -1.0f * P.damping; }
+    if (fabsf(p.y) > P.by) { p.y = P.by * sign_f32(p.y); v.y *= -1.0f * P.damping; }
+    if (fabsf(p.z) > P.bz) { p.z = P.bz * sign_f32(p.z); v.z *= -1.0f * P.damping; }
+    p.w = 0.0f; v.w = 0.0f;
+    pos_out[i] = p;
+    vel_out[i] = v;
+}
+
+__global__ __launch_bounds__(B3) void k3_export(uint32_t n, const float4* __restrict__ pos, const float4* __restrict__ pred,
+                                                const float4* __restrict__ vel, const uint32_t* __restrict__ key,
+                                                fs3_particle* __restrict__ out) {
+    const uint32_t i = blockIdx.x * B3 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pos[i], q = pred[i], v = vel[i];
+    fs3_particle a;
+    a.position = fs_vec3{p.x, p.y, p.z};
+    a.predicted_position = fs_vec3{q.x, q.y, q.z};
+    a.velocity = fs_vec3{v.x, v.y, v.z};
+    a.density = q.w; a.grid = key[i]; a.pad = 0;
+    out[i] = a;
+}
+__global__ __launch_bounds__(B3) void k3_import(uint32_t n, const fs3_particle* __restrict__ in, float4* __restrict__ pos,
+                                                float4* __restrict__ pred, float4* __restrict__ vel,
+                                                uint32_t* __restrict__ key) {
+    const uint32_t i = blockIdx.x * B3 + threadIdx.x;
+    if (i >= n) return;
+    const fs3_particle a = in[i];
+    pos[i] = make_float4(a.position.x, a.position.y, a.position.z, 0.0f);
+    pred[i] = make_float4(a.predicted_position.x, a.predicted_position.y, a.predicted_position.z, a.density);
+    vel[i] = make_float4(a.velocity.x, a.velocity.y, a.velocity.z, 0.0f);
+    key[i] = a.grid;
+}
+
+}  // namespace fsd
+
+// ------------------------------------------------------------------------------------ host
+namespace {
+fs_status fail3(fs_status st, const std::string& m) { fsd::set_last_error(m); return st; }
+template <class T> struct Dev3 {
+    T* p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t c) { n = c; return c ? hipMalloc((void**)&p, c * sizeof(T)) : hipSuccess; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+void lattice3(const fs3_settings& st, fs_vec3 off, fs3_particle* dst, size_t n) {
+    const uint32_t side = (uint32_t)std::llround(std::cbrt((double)st.particle_count));
+    const float half = (float)side * 0.5f, s = st.particle_spacing;
+    for (uint32_t i = 0; i < st.particle_count && i < n; ++i) {
+        const uint32_t ix = i % side, iy = (i / side) % side, iz = i / (side * side);
+        fs3_particle q;
+        std::memset(&q, 0, sizeof q);
+        q.position.x = ((float)ix - half + 0.5f) * s + off.x;
+        q.position.y = ((float)iy - half + 0.5f) * s + off.y;
+        q.position.z = ((float)iz - half + 0.5f) * s + off.z;
+        q.predicted_position = q.position;
+        dst[i] = q;
+    }
+}
+}  // namespace
+
+#define H3(expr)                                                                                         \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess)                                                                           \
+            return fail3(e__ == hipErrorOutOfMemory ? FS_ERR_OOM : FS_ERR_DEVICE,                        \
+                         std::string(#expr) + ": " + hipGetErrorString(e__));                            \
+    } while (0)
+
+struct fs_sim3 {
+    fs3_settings st{};
+    uint32_t n = 0, gw = 0, gh = 0, gd = 0, ncell = 0, tick = 0, work_cap = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Dev3<float4> pos, vel, pos_s, vel_s, pred;
+    Dev3<uint32_t> key, cs, counter, dirty;
+    Dev3<fsd::u64> pairs;
+    Dev3<unsigned char> work;
+    Dev3<fs3_particle> aos;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool profile = false;
+    std::vector<hipEvent_t> ev;
+    uint32_t pending = 0;
+    double ms[FS_PASS_COUNT] = {};
+    uint64_t steps = 0;
+    void release() {
+        pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); key.release(); cs.release();
+        counter.release(); dirty.release(); pairs.release(); work.release(); aos.release();
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static const uint32_t RING3 = 256;
+
+static fs_status drain3(fs_sim3* s) {
+    if (!s->pending) return FS_OK;
+    const size_t stride = FS_PASS_COUNT + 1;
+    H3(hipEventSynchronize(s->ev[(size_t)(s->pending - 1) * stride + FS_PASS_COUNT]));
+    for (uint32_t j = 0; j < s->pending; ++j)
+        for (int k = 0; k < FS_PASS_COUNT; ++k) {
+            float ms = 0;
+            H3(hipEventElapsedTime(&ms, s->ev[j * stride + k], s->ev[j * stride + k + 1]));
+            s->ms[k] += ms;
+        }
+    s->steps += s->pending;
+    s->pending = 0;
+    return FS_OK;
+}
+
+static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
+    using namespace fsd;
+    s->tick += 1;
+    const float h = s->st.smoothing_radius;
+    const float PI3 = 3.14159265359f;
+    Params3 P;
+    std::memset(&P, 0, sizeof P);
+    P.n = s->n; P.gw = s->gw; P.gh = s->gh; P.gd = s->gd; P.ncell = s->ncell;
+    P.dt = t->delta; P.h = h; P.h2 = h * h;
+    P.bx = s->st.size.x * 0.5f; P.by = s->st.size.y * 0.5f; P.bz = s->st.size.z * 0.5f;
+    P.mass = t->mass;
+    P.poly6 = 315.0f / (64.0f * PI3 * std::pow(h, 9.0f));      // host libm, as in the oracle
+    P.spiky = 15.0f / (PI3 * std::pow(h, 5.0f));
+    P.visc_k = 15.0f / (2.0f * PI3 * (h * h * h));
+    P.pressure_k = t->pressure_constant; P.rest_density = t->rest_density; P.damping = t->damping_factor;
+    P.visc_coeff = t->viscosity_coefficient;
+    P.gx = t->gravity.x; P.gy = t->gravity.y; P.gz = t->gravity.z;
+    P.frame = s->tick;
+    hipStream_t st = s->stream;
+    hipEvent_t* ev = nullptr;
+    if (s->profile) {
+        if (s->ev.empty()) { s->ev.resize((size_t)RING3 * (FS_PASS_COUNT + 1)); for (auto& e : s->ev) H3(hipEventCreate(&e)); }
+        if (s->pending == RING3) { fs_status r = drain3(s); if (r != FS_OK) return r; }
+        ev = &s->ev[(size_t)s->pending * (FS_PASS_COUNT + 1)];
+    }
+    const dim3 grid((s->n + B3 - 1) / B3), block(B3);
+    if (ev) H3(hipEventRecord(ev[0], st));
+    hipLaunchKernelGGL(k3_predict_key, grid, block, 0, st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
+    if (ev) H3(hipEventRecord(ev[1], st));
+    launch_bitonic_sort(st, s->pairs.p, s->n, s->dirty.p);
+    if (ev) H3(hipEventRecord(ev[2], st));
+    hipLaunchKernelGGL(k3_reorder, grid, block, 0, st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p,
+                       s->pred.p, s->key.p, s->cs.p, (GapEntry*)s->work.p, s->counter.p, s->work_cap);
+    launch_fill_gaps(st, s->cs.p, s->work.p, s->counter.p, s->work_cap);
+    if (ev) H3(hipEventRecord(ev[3], st));
+    hipLaunchKernelGGL(k3_density, grid, block, 0, st, P, s->pred.p, s->cs.p);
+    if (ev) H3(hipEventRecord(ev[4], st));
+    hipLaunchKernelGGL(k3_force, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p);
+    if (ev) { H3(hipEventRecord(ev[5], st)); s->pending += 1; }
+    H3(hipGetLastError());
+    return FS_OK;
+}
+
+extern "C" {
+
+fs_status fs3_reference_lattice(const fs3_settings* st, fs_vec3 off, fs3_particle* dst, size_t n) {
+    if (!st || (!dst && n)) return fail3(FS_ERR_INVALID, "null argument");
+    lattice3(*st, off, dst, n);
+    return FS_OK;
+}
+
+fs_status fs3_create(const fs3_settings* st, int device, fs_vec3 off, fs_sim3** out) {
+    if (!st || !out) return fail3(FS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (st->particle_count <= 1) return fail3(FS_ERR_INVALID, "particle_count <= 1");
+    if (!(st->smoothing_radius > 0.0f) || !(st->size.x > 0) || !(st->size.y > 0) || !(st->size.z > 0))
+        return fail3(FS_ERR_INVALID, "bad settings");
+    const uint32_t side = (uint32_t)std::llround(std::cbrt((double)st->particle_count));
+    if ((uint64_t)side * side * side != st->particle_count) return fail3(FS_ERR_INVALID, "particle_count must be a cube");
+    const double gw = std::ceil((double)st->size.x / st->smoothing_radius) + 2, gh = std::ceil((double)st->size.y / st->smoothing_radius) + 2,
+                 gd = std::ceil((double)st->size.z / st->smoothing_radius) + 2;
+    if (gw * gh * gd >= 4294967295.0) return fail3(FS_ERR_INVALID, "grid does not fit u32 cell ids");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail3(FS_ERR_DEVICE, "no HIP device: the engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail3(FS_ERR_INVALID, "device ordinal out of range");
+    H3(hipSetDevice(device));
+    fs_sim3* s = new (std::nothrow) fs_sim3();
+    if (!s) return fail3(FS_ERR_OOM, "host allocation failed");
+    s->st = *st; s->n = st->particle_count; s->device = device;
+    s->gw = (uint32_t)((size_t)std::ceil(st->size.x / st->smoothing_radius) + 2);
+    s->gh = (uint32_t)((size_t)std::ceil(st->size.y / st->smoothing_radius) + 2);
+    s->gd = (uint32_t)((size_t)std::ceil(st->size.z / st->smoothing_radius) + 2);
+    s->ncell = s->gw * s->gh * s->gd;
+    s->work_cap = s->ncell / 16u + 1024u;
+#define T3(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { s->release(); delete s; return fail3(FS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+    T3(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const size_t n = s->n;
+    T3(s->pos.alloc(n)); T3(s->vel.alloc(n)); T3(s->pos_s.alloc(n)); T3(s->vel_s.alloc(n)); T3(s->pred.alloc(n));
+    T3(s->key.alloc(n)); T3(s->pairs.alloc(n)); T3(s->cs.alloc((size_t)s->ncell + 1)); T3(s->counter.alloc(4));
+    T3(s->dirty.alloc(fsd::sort_tile_count((uint32_t)n))); T3(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
+    T3(s->aos.alloc(n));
+    T3(hipEventCreate(&s->t0)); T3(hipEventCreate(&s->t1));
+    T3(hipMemsetAsync(s->cs.p, 0, s->cs.n * 4, s->stream));
+    T3(hipMemsetAsync(s->counter.p, 0, 16, s->stream));
+    T3(hipMemsetAsync(s->dirty.p, 0, s->dirty.n * 4, s->stream));
+    {
+        std::vector<fs3_particle> host(n);
+        lattice3(*st, off, host.data(), n);
+        T3(hipMemcpyAsync(s->aos.p, host.data(), n * sizeof(fs3_particle), hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(fsd::k3_import, dim3((s->n + B3 - 1) / B3), dim3(B3), 0, s->stream, s->n, s->aos.p, s->pos.p,
+                           s->pred.p, s->vel.p, s->key.p);
+        T3(hipStreamSynchronize(s->stream));
+    }
+#undef T3
+    *out = s;
+    return FS_OK;
+}
+
+void fs3_destroy(fs_sim3* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    s->release();
+    delete s;
+}
+
+fs_status fs3_step(fs_sim3* s, const fs3_tick_settings* t) {
+    if (!s || !t) return fail3(FS_ERR_INVALID, "null argument");
+    H3(hipSetDevice(s->device));
+    return enqueue3(s, t);
+}
+fs_status fs3_sync(fs_sim3* s) { if (!s) return fail3(FS_ERR_INVALID, "null"); H3(hipStreamSynchronize(s->stream)); return FS_OK; }
+uint32_t fs3_tick_count(const fs_sim3* s) { return s ? s->tick : 0; }
+uint32_t fs3_particle_count(const fs_sim3* s) { return s ? s->n : 0; }
+fs_status fs3_grid_dims(const fs_sim3* s, uint32_t* w, uint32_t* h, uint32_t* d) {
+    if (!s || !w || !h || !d) return fail3(FS_ERR_INVALID, "null argument");
+    *w = s->gw; *h = s->gh; *d = s->gd;
+    return FS_OK;
+}
+fs_status fs3_download_particles(fs_sim3* s, fs3_particle* dst, size_t n) {
+    if (!s || (!dst && n)) return fail3(FS_ERR_INVALID, "null argument");
+    if (n > s->n) n = s->n;
+    H3(hipSetDevice(s->device));
+    hipLaunchKernelGGL(fsd::k3_export, dim3((s->n + B3 - 1) / B3), dim3(B3), 0, s->stream, s->n, s->pos.p, s->pred.p,
+                       s->vel.p, s->key.p, s->aos.p);
+    if (n) H3(hipMemcpyAsync(dst, s->aos.p, n * sizeof(fs3_particle), hipMemcpyDeviceToHost, s->stream));
+    H3(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+fs_status fs3_upload_particles(fs_sim3* s, const fs3_particle* src, size_t n) {
+    if (!s || (!src && n)) return fail3(FS_ERR_INVALID, "null argument");
+    if (n > s->n) n = s->n;
+    H3(hipSetDevice(s->device));
+    if (n) H3(hipMemcpyAsync(s->aos.p, src, n * sizeof(fs3_particle), hipMemcpyHostToDevice, s->stream));
+    if (n) hipLaunchKernelGGL(fsd::k3_import, dim3(((uint32_t)n + B3 - 1) / B3), dim3(B3), 0, s->stream, (uint32_t)n,
+                              s->aos.p, s->pos.p, s->pred.p, s->vel.p, s->key.p);
+    H3(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+fs_status fs3_timed_steps(fs_sim3* s, const fs3_tick_settings* t, uint32_t steps, double* ms_total) {
+    if (!s || !t || !ms_total) return fail3(FS_ERR_INVALID, "null argument");
+    H3(hipSetDevice(s->device));
+    H3(hipEventRecord(s->t0, s->stream));
+    for (uint32_t k = 0; k < steps; ++k) { fs_status r = enqueue3(s, t); if (r != FS_OK) return r; }
+    H3(hipEventRecord(s->t1, s->stream));
+    H3(hipEventSynchronize(s->t1));
+    float ms = 0;
+    H3(hipEventElapsedTime(&ms, s->t0, s->t1));
+    *ms_total = ms;
+    return FS_OK;
+}
+fs_status fs3_profile_enable(fs_sim3* s, int enable) { if (!s) return fail3(FS_ERR_INVALID, "null"); s->profile = enable != 0; return FS_OK; }
+fs_status fs3_profile_read(fs_sim3* s, double ms[FS_PASS_COUNT], uint64_t* steps, int reset) {
+    if (!s || !ms) return fail3(FS_ERR_INVALID, "null argument");
+    fs_status r = drain3(s);
+    if (r != FS_OK) return r;
+    for (int k = 0; k < FS_PASS_COUNT; ++k) ms[k] = s->ms[k];
+    if (steps) *steps = s->steps;
+    if (reset) { for (auto& m : s->ms) m = 0; s->steps = 0; }
+    return FS_OK;
+}
+
+}  // extern "C"

@@ -239,6 +239,52 @@ fs_status fs_slab_download(fs_sim* sim, fs_particle* dst, uint8_t* owned, size_t
 /* Per-global-column particle counts of the owned columns (others untouched); blocking. */
 fs_status fs_slab_column_histogram(fs_sim* sim, uint32_t* hist, size_t grid_w_global);
 
+/* ------------------------------------------------------------ 3D extension */
+/* NOT in the reference (2D only).  Build-defined per SURVEY.md Appendix B.3: same pass
+ * chain and kernel shapes with a third coordinate, 27-cell sweep, clean cell starts, no
+ * mouse force / obstacle field.  Normative statement: oracle/sph_oracle3d.cpp. */
+typedef struct fs3_settings {
+    uint32_t particle_count;      /* must be a cube (side^3) for the built-in lattice */
+    float particle_spacing;
+    float smoothing_radius;
+    fs_vec3 size;
+} fs3_settings;
+
+typedef struct fs3_tick_settings {
+    float delta;
+    fs_vec3 gravity;
+    float mass;
+    float pressure_constant;
+    float rest_density;
+    float damping_factor;
+    float viscosity_coefficient;
+} fs3_tick_settings;
+
+typedef struct fs3_particle {      /* 48 bytes */
+    fs_vec3 position;
+    fs_vec3 predicted_position;
+    fs_vec3 velocity;
+    float density;
+    uint32_t grid;
+    uint32_t pad;
+} fs3_particle;
+
+typedef struct fs_sim3 fs_sim3;
+
+fs_status fs3_create(const fs3_settings* settings, int device, fs_vec3 initial_offset, fs_sim3** out);
+void fs3_destroy(fs_sim3* sim);
+fs_status fs3_step(fs_sim3* sim, const fs3_tick_settings* tick);
+fs_status fs3_sync(fs_sim3* sim);
+uint32_t fs3_tick_count(const fs_sim3* sim);
+uint32_t fs3_particle_count(const fs_sim3* sim);
+fs_status fs3_grid_dims(const fs_sim3* sim, uint32_t* w, uint32_t* h, uint32_t* d);
+fs_status fs3_download_particles(fs_sim3* sim, fs3_particle* dst, size_t n);
+fs_status fs3_upload_particles(fs_sim3* sim, const fs3_particle* src, size_t n);
+fs_status fs3_reference_lattice(const fs3_settings* settings, fs_vec3 offset, fs3_particle* dst, size_t n);
+fs_status fs3_timed_steps(fs_sim3* sim, const fs3_tick_settings* tick, uint32_t steps, double* ms_total);
+fs_status fs3_profile_enable(fs_sim3* sim, int enable);
+fs_status fs3_profile_read(fs_sim3* sim, double ms[FS_PASS_COUNT], uint64_t* steps, int reset);
+
 /* ------------------------------------------------------- ResizableBuffer */
 /* ResizableBuffer<T>::new (src/buffer.rs:27-43). */
 fs_status fs_buffer_create(int device, size_t elem_size, size_t len, const char* name, fs_buffer** out);

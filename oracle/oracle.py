@@ -64,8 +64,69 @@ def lib():
         L.orc_bitonic_keys.argtypes = [P, P, C.c_uint32]
         L.orc_poly6_value.restype = C.c_float
         L.orc_poly6_value.argtypes = [C.c_float, C.c_float]
+        L.orc3_create.restype = P
+        L.orc3_create.argtypes = [P, C.c_float, C.c_float, C.c_float]
+        L.orc3_destroy.argtypes = [P]
+        L.orc3_step.argtypes = [P, P]
+        L.orc3_particles.restype = P
+        L.orc3_particles.argtypes = [P]
+        L.orc3_count.restype = C.c_uint32
+        L.orc3_count.argtypes = [P]
+        L.orc3_grid.argtypes = [P, P, P, P]
+        L.orc3_constants.argtypes = [P, P]
+        L.orc3_lattice.argtypes = [P, C.c_float, C.c_float, C.c_float, P, C.c_size_t]
         _lib = L
     return _lib
+
+
+PARTICLE3_DTYPE = np.dtype([("position", "<f4", (3,)), ("predicted_position", "<f4", (3,)), ("velocity", "<f4", (3,)),
+                            ("density", "<f4"), ("grid", "<u4"), ("pad", "<u4")])
+
+
+class OracleSim3D:
+    """3D oracle (oracle/sph_oracle3d.cpp); no reference counterpart."""
+
+    def __init__(self, settings, initial_offset=(0.0, 0.0, 0.0)):
+        self.L = lib()
+        self.h = self.L.orc3_create(C.addressof(settings), *[float(x) for x in initial_offset])
+        if not self.h:
+            raise ValueError("oracle3d: invalid settings")
+        self.n = int(self.L.orc3_count(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.orc3_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, tick):
+        self.L.orc3_step(self.h, C.addressof(tick))
+
+    def particles_view(self):
+        buf = (C.c_char * (self.n * 48)).from_address(self.L.orc3_particles(self.h))
+        return np.frombuffer(buf, dtype=PARTICLE3_DTYPE)
+
+    def particles(self):
+        return self.particles_view().copy()
+
+    def set_particles(self, arr):
+        self.particles_view()[:] = np.ascontiguousarray(arr, dtype=PARTICLE3_DTYPE)
+
+    @property
+    def grid_dims(self):
+        w, h, d = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.L.orc3_grid(self.h, C.addressof(w), C.addressof(h), C.addressof(d))
+        return int(w.value), int(h.value), int(d.value)
+
+    def constants(self):
+        out = (C.c_float * 3)()
+        self.L.orc3_constants(self.h, C.addressof(out))
+        return tuple(out)
 
 
 class OracleSim:

@@ -1,0 +1,115 @@
+"""3D extension (27-cell path).  The reference is 2D only: the oracle here is this repo's own
+statement (oracle/sph_oracle3d.cpp) — parity with a reference is undefined;
+what is pinned: analytic kernel constants / interior lattice density, and HIP == oracle bit for bit."""
+import numpy as np
+import pytest
+
+FLOATS = ("position", "predicted_position", "velocity", "density")
+
+
+def test_oracle3d_known_answers(fs, orc):
+    # h = 0.2: 315/(64 pi h^9) = 3.05992e6, 15/(pi h^5) = 14920.8, 15/(2 pi h^3) = 298.4155
+    st = fs.Settings3(12 ** 3, 0.1, 0.2, fs.Vec3(20.0, 20.0, 20.0))
+    tick = fs.TickSettings3(float(np.float32(1) / np.float32(120)), fs.Vec3(0, 0, 0), 1.0, 50.0, 0.0, 0.1, 25.0)
+    o = orc.OracleSim3D(st)
+    assert o.grid_dims == (102, 102, 102)
+    o.step(tick)
+    poly6, spiky, visc = o.constants()
+    assert poly6 == pytest.approx(3.0599245e6, rel=2e-6)
+    assert spiky == pytest.approx(14920.775, rel=2e-6)
+    assert visc == pytest.approx(298.41552, rel=2e-6)
+    # interior lattice particle, s = 0.1: W(0) + 6 W(0.1) + 12 W(0.1 sqrt2) + 8 W(0.1 sqrt3) + 6 W(0.2)=0
+    h2 = 0.04
+    want = poly6 * (h2 ** 3 + 6 * (h2 - 0.01) ** 3 + 12 * (h2 - 0.02) ** 3 + 8 * (h2 - 0.03) ** 3)
+    assert o.particles()["density"].max() == pytest.approx(want, rel=1e-4)
+    p = o.particles()
+    assert np.all(p["grid"][:-1] <= p["grid"][1:])
+
+
+def test_oracle3d_lattice_and_invariants(fs, orc):
+    st, off, tick = fs.dam_break_3d(10 ** 3)
+    o = orc.OracleSim3D(st, off)
+    p0 = o.particles()
+    assert np.unique(p0["position"], axis=0).shape[0] == 1000
+    assert p0["position"][:, 0].min() == pytest.approx(-st.size.x / 2 + 0.1, abs=1e-5)   # one spacing off the wall
+    for _ in range(60):
+        o.step(tick)
+    p = o.particles()
+    assert np.isfinite(p["position"]).all() and np.isfinite(p["velocity"]).all()
+    for a, b in enumerate((st.size.x, st.size.y, st.size.z)):
+        assert np.abs(p["position"][:, a]).max() <= b / 2
+    assert p["density"].min() >= np.float32(0.1)
+
+
+def test_lattice3d_matches_oracle(fs, orc):
+    import ctypes as C
+    st, off, tick = fs.dam_break_3d(9 ** 3)
+    got = fs.reference_lattice_3d(st, off)
+    want = np.zeros(9 ** 3, dtype=fs.PARTICLE3_DTYPE)
+    orc.lib().orc3_lattice(C.addressof(st), off[0], off[1], off[2], want.ctypes.data, want.shape[0])
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+def _assert_equal3(got, want, ctx):
+    assert np.array_equal(got["grid"], want["grid"]), f"{ctx}: cell keys differ"
+    for f in FLOATS:
+        a, b = got[f].view(np.uint32), want[f].view(np.uint32)
+        if not np.array_equal(a, b):
+            err = np.abs(got[f].astype(np.float64) - want[f].astype(np.float64)).max()
+            raise AssertionError(f"{ctx}: {f} not bit-exact ({int((a != b).sum())} words), max abs err {err:g}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,seed,steps", [(16, None, 10), (20, 5, 5), (3, 1, 4), (33, 9, 2)])
+def test_3d_parity_with_oracle(fs, orc, side, seed, steps):
+    n = side ** 3
+    st, off, tick = fs.dam_break_3d(n)
+    sim = fs.FluidSimulation3D(st, device=0, initial_offset=off)
+    ref = orc.OracleSim3D(st, off)
+    if seed is not None:
+        rng = np.random.default_rng(seed)
+        p = ref.particles()
+        p["position"] += rng.uniform(-0.025, 0.025, size=(n, 3)).astype(np.float32)
+        p["predicted_position"] = p["position"]
+        p["velocity"] = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        ref.set_particles(p)
+        sim.upload_particles(p)
+    assert sim.grid_dims == ref.grid_dims
+    _assert_equal3(sim.download_particles(), ref.particles(), "initial")
+    for s in range(steps):
+        sim.tick(tick)
+        ref.step(tick)
+        _assert_equal3(sim.download_particles(), ref.particles(), f"3d side {side} step {s}")
+    assert sim.tick_count == steps
+
+
+@pytest.mark.gpu
+def test_3d_coincident_and_guards(fs, orc):
+    n = 12 ** 3
+    st, off, tick = fs.dam_break_3d(n)
+    sim = fs.FluidSimulation3D(st, device=0, initial_offset=off)
+    ref = orc.OracleSim3D(st, off)
+    p = ref.particles()
+    p["position"][1:4] = p["position"][0]
+    p["predicted_position"][1:4] = p["position"][0]
+    p["velocity"][7] = (np.nan, 0, 1)
+    p["velocity"][9] = (9000, -9000, 100)
+    ref.set_particles(p); sim.upload_particles(p)
+    for s in range(3):
+        sim.tick(tick); ref.step(tick)
+        _assert_equal3(sim.download_particles(), ref.particles(), f"guards step {s}")
+
+
+@pytest.mark.gpu
+def test_3d_8m_properties(fs):
+    """BASELINE configs[3] size: sortedness, finite state, analytic interior density."""
+    n = 200 ** 3
+    st, off, tick = fs.dam_break_3d(n)
+    sim = fs.FluidSimulation3D(st, device=0, initial_offset=off)
+    assert sim.grid_dims == (202, 127, 103)
+    for _ in range(3):
+        sim.tick(tick)
+    p = sim.download_particles()
+    assert np.all(p["grid"][:-1] <= p["grid"][1:])
+    assert np.isfinite(p["position"]).all() and np.isfinite(p["velocity"]).all()
+    assert np.median(p["density"]) == pytest.approx(1009.8, rel=2e-3)
