@@ -109,6 +109,7 @@ struct fs_sim {
     DevArray<uint32_t> key;
     DevArray<fsd::u64> pairs;
     DevArray<uint32_t> sort_dirty;  // per-tile flags of the bitonic sort
+    DevArray<uint32_t> csort;       // scratch of the counting sort (FS_SORT_COUNTING)
     DevArray<uint32_t> cs;          // dense cell-start table, ncell+1
     DevArray<uint32_t> start_ref;   // reference start_indices (persistent, never cleared)
     DevArray<float2> tex;           // force field
@@ -139,7 +140,7 @@ struct fs_sim {
 
     void release() {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release();
-        key.release(); pairs.release(); sort_dirty.release(); cs.release(); start_ref.release(); tex.release(); work.release();
+        key.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
         owned.release(); flags.release(); blockcnt.release(); blockoff.release(); slab_counters.release();
         hist.release();
@@ -289,16 +290,17 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     if (s->n == 0) return FS_OK;
 
     if (prof) FS_HIP(hipEventRecord(ev[0], st));
-    fsd::launch_predict_key(st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
+    const bool counting = s->opts.sort_mode == FS_SORT_COUNTING;
+    if (!counting) fsd::launch_predict_key(st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
     if (prof) FS_HIP(hipEventRecord(ev[1], st));
-    if (s->opts.sort_mode == FS_SORT_BITONIC) {
-        fsd::launch_bitonic_sort(st, s->pairs.p, s->n, s->sort_dirty.p);
+    if (counting) {
+        fsd::launch_counting_sort(st, P, s->pos.p, s->vel.p, s->pairs.p, s->cs.p, s->csort.p, s->counter.p);
     } else {
-        return fail(FS_ERR_UNSUPPORTED, "sort_mode not built");
+        fsd::launch_bitonic_sort(st, s->pairs.p, s->n, s->sort_dirty.p);
     }
     if (prof) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, s->key.p, s->cs.p,
-                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap);
+                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap, counting);
     if (prof) FS_HIP(hipEventRecord(ev[3], st));
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
@@ -378,6 +380,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     FS_TRY(s->tex.alloc((size_t)settings->texture_size.x * settings->texture_size.y));
     FS_TRY(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
     FS_TRY(s->counter.alloc(4));
+    if (opts->sort_mode == FS_SORT_COUNTING) FS_TRY(s->csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
     FS_TRY(hipEventCreate(&s->t0));
     FS_TRY(hipEventCreate(&s->t1));
     // wgpu zero-initialises buffers: start_indices (simulation.rs:204-209), force field (:213-218)

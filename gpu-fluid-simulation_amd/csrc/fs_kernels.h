@@ -12,7 +12,7 @@ void launch_predict_key(hipStream_t st, const StepParams& P, const float2* pos, 
                         uint32_t* gap_counter);
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
-                    void* work, uint32_t* counter, uint32_t work_cap);
+                    void* work, uint32_t* counter, uint32_t work_cap, bool cs_ready = false);
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
                     const uint32_t* start_ref, const u64* pairs, float* rho);
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
@@ -48,5 +48,10 @@ size_t slab_message_bytes(uint32_t R);
 // `dirty`: one u32 per 4096-element tile (sort_tile_count(n) entries), scratch owned by the caller.
 int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty);
 uint32_t sort_tile_count(uint32_t n);
+
+// FS_SORT_COUNTING (kernels_csort.hip): fills `pairs` (stable order) and the dense table `cs`.
+size_t counting_sort_scratch_words(uint32_t n, uint32_t ncell);
+void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, u64* pairs,
+                          uint32_t* cs, uint32_t* scratch, uint32_t* gap_counter);
 
 }  // namespace fsd

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_fill_gaps(uint32_t* __restrict__ c
 // Gathers the payload into cell order (the reference swaps whole 32-byte records
 // inside the sort, sort.wgsl:44-50; sorting (key,index) pairs and gathering once
 // gives the identical arrangement because the network only looks at keys).
+template <bool FILL>
 __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* __restrict__ pairs,
                                                       const float2* __restrict__ pos_in,
                                                       const float2* __restrict__ vel_in, float2* __restrict__ pos_s,
@@ -67,16 +68,16 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
     const uint32_t kc = key < P.ncell ? key : P.ncell;   // clamp for table writes only
     if (i == 0) {
         if (!P.ref_quirks && key < P.ncell) start_ref[key] = 0;   // compute.wgsl:50 skips index 0
-        fill_cells(cs, 0u, kc + 1u > P.ncell + 1u ? P.ncell + 1u : kc + 1u, 0u, work, counter, work_cap);
+        if (FILL) fill_cells(cs, 0u, kc + 1u, 0u, work, counter, work_cap);
     } else {
         const uint32_t prev = (uint32_t)(pairs[i - 1] >> 32);
         if (key != prev) {
             if (key < P.ncell) start_ref[key] = i;                // compute.wgsl:53-55
             const uint32_t pc = prev < P.ncell ? prev : P.ncell;
-            fill_cells(cs, pc + 1u, kc + 1u, i, work, counter, work_cap);
+            if (FILL) fill_cells(cs, pc + 1u, kc + 1u, i, work, counter, work_cap);
         }
     }
-    if (i == P.n - 1) fill_cells(cs, kc + 1u, P.ncell + 1u, P.n, work, counter, work_cap);
+    if (FILL && i == P.n - 1) fill_cells(cs, kc + 1u, P.ncell + 1u, P.n, work, counter, work_cap);
 }
 
 // ------------------------------------------------------------ neighbour ranges
@@ -518,8 +519,13 @@ void launch_predict_key(hipStream_t st, const StepParams& P, const float2* pos, 
 
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
-                    void* work, uint32_t* counter, uint32_t work_cap) {
-    hipLaunchKernelGGL(k_reorder, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pairs, pos_in, vel_in, pos_s, vel_s,
+                    void* work, uint32_t* counter, uint32_t work_cap, bool cs_ready) {
+    if (cs_ready) {   // counting sort already produced the dense table
+        hipLaunchKernelGGL(k_reorder<false>, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pairs, pos_in, vel_in, pos_s,
+                           vel_s, pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap);
+        return;
+    }
+    hipLaunchKernelGGL(k_reorder<true>, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pairs, pos_in, vel_in, pos_s, vel_s,
                        pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap);
     hipLaunchKernelGGL(k_fill_gaps, dim3(1024), dim3(FS_BLOCK), 0, st, cs, (const GapEntry*)work, counter, work_cap);
 }

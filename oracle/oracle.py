@@ -40,6 +40,7 @@ def lib():
         L.orc_begin_tick.argtypes = [P, P]
         L.orc_density.argtypes = [P, C.c_int]
         L.orc_step.argtypes = [P, P]
+        L.orc_step_stable.argtypes = [P, P]
         L.orc_tick.restype = C.c_uint32
         L.orc_tick.argtypes = [P]
         L.orc_count.restype = C.c_uint32
@@ -153,8 +154,8 @@ class OracleSim:
         except Exception:
             pass
 
-    def step(self, tick):
-        self.L.orc_step(self.h, C.addressof(tick))
+    def step(self, tick, stable_sort=False):
+        (self.L.orc_step_stable if stable_sort else self.L.orc_step)(self.h, C.addressof(tick))
 
     # individual passes (reference dispatch order, src/simulation.rs:512-537)
     def begin_tick(self, tick): self.L.orc_begin_tick(self.h, C.addressof(tick))

@@ -16,6 +16,7 @@
  * the reference tree).  All arithmetic is IEEE f32, evaluated in the written
  * association; build with -ffp-contract=off (see oracle/Makefile).
  */
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -471,9 +472,25 @@ void orc_sort(orc_sim* h) {
     OrcSim& s = *(OrcSim*)h;
     bitonic_network(s.p.data(), s.u.particle_count, [](const fs_particle& q) { return q.grid; });
 }
+/* FS_SORT_COUNTING counterpart (NOT the reference's sort): stable sort by cell key. */
+void orc_sort_stable(orc_sim* h) {
+    OrcSim& s = *(OrcSim*)h;
+    std::stable_sort(s.p.begin(), s.p.begin() + s.u.particle_count,
+                     [](const fs_particle& a, const fs_particle& b) { return a.grid < b.grid; });
+}
 void orc_cell_starts(orc_sim* h) { cell_starts(*(OrcSim*)h); }
 void orc_density(orc_sim* h, int reach) { density(*(OrcSim*)h, reach); }
 void orc_move(orc_sim* h) { move_particles(*(OrcSim*)h); }
+
+void orc_step_stable(orc_sim* h, const fs_tick_settings* t) {   /* step with the stable sort */
+    orc_begin_tick(h, t);
+    orc_predict(h);
+    orc_spatial_lookup(h);
+    orc_sort_stable(h);
+    orc_cell_starts(h);
+    orc_density(h, 1);
+    orc_move(h);
+}
 
 void orc_step(orc_sim* h, const fs_tick_settings* t) {
     orc_begin_tick(h, t);

@@ -254,3 +254,40 @@ def test_16m_properties(fs):
     interior = np.median(p["density"])
     assert interior == pytest.approx(101.46, rel=1e-3)
     assert np.abs(p["position"][:, 0]).max() <= st.size.x / 2 and np.abs(p["position"][:, 1]).max() <= st.size.y / 2
+
+
+@pytest.mark.parametrize("n,seed,steps", [(4096, None, 20), (5000, 3, 5), (100_000, 8, 3), (1 << 20, None, 2)])
+def test_counting_sort_mode_matches_stable_oracle(fs, orc, n, seed, steps):
+    """FS_SORT_COUNTING is a stable cell sort: bit-exact against the oracle run
+    with std::stable_sort in place of the network (keys, start_indices and floats)."""
+    if seed is None:
+        st, off, tick = fs.dam_break_2d(n)
+    else:
+        side = float(np.ceil(np.sqrt(n))) * 0.1
+        st = fs.SimulationSettings(n, 0.1, 0.2, (2.0 * side, 1.5 * side))      # roomy box: no wall pile-up
+        off, tick = (0.0, 0.0), fs.default_tick_settings(gravity=(0.0, 9.81))
+    sim = fs.FluidSimulation(st, device=0, initial_offset=off, sort_mode=fs.FS_SORT_COUNTING)
+    ref = orc.OracleSim(st, off)
+    if seed is not None:
+        rng = np.random.default_rng(seed)
+        p = ref.particles()
+        p["position"] += rng.uniform(-0.025, 0.025, size=(n, 2)).astype(np.float32)
+        p["predicted_position"] = p["position"]
+        p["velocity"] = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        ref.set_particles(p); sim.upload_particles(p)
+    for s in range(steps):
+        sim.tick(tick)
+        ref.step(tick, stable_sort=True)
+        assert_particles_equal(sim.download_particles(), ref.particles(), f"counting n={n} step {s}")
+        assert np.array_equal(sim.download_start_indices(), ref.start_indices())
+
+
+def test_counting_vs_bitonic_within_tolerance(fs):
+    """The two sort modes differ only in the order inside a cell -> summation order -> ULPs."""
+    from tests.slab_oracle import match_and_compare
+    st, off, tick = fs.dam_break_2d(16384)
+    a = fs.FluidSimulation(st, device=0, initial_offset=off, sort_mode=fs.FS_SORT_BITONIC)
+    b = fs.FluidSimulation(st, device=0, initial_offset=off, sort_mode=fs.FS_SORT_COUNTING)
+    for _ in range(4):
+        a.tick(tick); b.tick(tick)
+    match_and_compare(b.download_particles(), a.download_particles(), st.smoothing_radius)
