@@ -120,11 +120,17 @@ def main():
         gbs = alg_bytes[name] * n / (t * 1e-3) / 1e9 if t > 0 else 0.0
         per_pass[name] = {"ms": round(t, 4), "alg_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
     dom = max(per_pass, key=lambda k: per_pass[k]["ms"])
+    traffic = args.pmc_traffic
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if traffic is None and not is3d and args.workload == "dam_break_2d_16M" and os.path.exists(tpath):
+        # HBM bytes per step of the dominant pass from the committed rocprofv3 --pmc runs (separate
+        # FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction): profiles/traffic_latest.json
+        traffic = json.load(open(tpath))["bytes_per_step_by_pass"].get(dom)
     roofline = {
         "bound": "hbm", "kernel": dom,
         "achieved": per_pass[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": per_pass[dom]["frac"],
-        "traffic": args.pmc_traffic,
+        "traffic": traffic,
         "alg_bytes_per_particle": alg_bytes[dom],
         "step": {"alg_bytes_per_particle": alg_total,
                  "achieved": round(alg_total * n / (ms_per_step * 1e-3) / 1e9, 1),
