@@ -114,7 +114,7 @@ def test_slab_rebalancing_keeps_parity_and_conserves(fs):
 def test_two_rank_bench_rehearsal_gloo(fs):
     """bench.py --gpus 2 launched as two ranks that share GPU 0 (RCCL refuses two ranks on one
     device, so the rehearsal uses gloo with host-staged messages; the driver's real run uses nccl)."""
-    env = dict(os.environ, FS_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    env = dict(os.environ, FS_DIST_BACKEND="gloo", OMP_NUM_THREADS="2", FS_REBALANCE_EVERY="3")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2",
            "--workload", "dam_break_2d_1M", "--no-cpu-baseline"]
