@@ -301,12 +301,13 @@ class SlabSimulation:
     messages with the slab neighbours -> step(); see multi.py for the driver.
     """
 
-    def __init__(self, settings, own_lo, own_hi, has_left, has_right, capacity, recv_capacity, max_cols, device=0):
+    def __init__(self, settings, own_lo, own_hi, has_left, has_right, capacity, recv_capacity, max_cols, device=0,
+                 sort_mode=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.settings = settings
         self.cfg = SlabConfig(int(own_lo), int(own_hi), int(bool(has_left)), int(bool(has_right)), int(capacity),
-                              int(recv_capacity), int(max_cols), 0)
+                              int(recv_capacity), int(max_cols), 0 if sort_mode is None else 1 + int(sort_mode))
         _check(self._lib, self._lib.fs_slab_create(C.byref(settings), int(device), C.byref(self.cfg), C.byref(self._h)))
         self.capacity = int(capacity)
         self.message_bytes = int(self._lib.fs_slab_message_bytes(self._h))

@@ -125,7 +125,7 @@ class SlabConfig(C.Structure):
         ("own_lo", C.c_uint32), ("own_hi", C.c_uint32),
         ("has_left", C.c_uint32), ("has_right", C.c_uint32),
         ("capacity", C.c_uint32), ("recv_capacity", C.c_uint32),
-        ("max_cols", C.c_uint32), ("reserved", C.c_uint32),
+        ("max_cols", C.c_uint32), ("sort_mode", C.c_uint32),
     ]
 
 

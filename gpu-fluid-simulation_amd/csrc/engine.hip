@@ -598,6 +598,9 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     fs_options_default(&s->opts);
     s->opts.device = device;
     s->opts.ref_quirks = 0;
+    // per-rank sorts can only be tolerance-parity with a single-domain run, so slabs
+    // default to the O(N) counting sort; cfg->sort_mode = 1 + FS_SORT_BITONIC selects the network
+    s->opts.sort_mode = cfg->sort_mode == 1 + FS_SORT_BITONIC ? FS_SORT_BITONIC : FS_SORT_COUNTING;
     s->device = device;
     s->slab = true;
     s->slab_cfg = *cfg;
@@ -627,6 +630,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(s->blockcnt.alloc(nblocks)); FS_TRY(s->blockoff.alloc(nblocks));
     FS_TRY(s->slab_counters.alloc(8));
     FS_TRY(s->hist.alloc(gw));
+    FS_TRY(s->csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1)); FS_TRY(s->start_ref.alloc(s->ncell));
     FS_TRY(s->tex.alloc((size_t)settings->texture_size.x * settings->texture_size.y));
     FS_TRY(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
@@ -719,11 +723,17 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
                             s->slab_cfg.has_right ? recv_right : nullptr, s->pos.p, s->vel.p, s->pairs.p,
                             s->slab_counters.p);
     if (ev) FS_HIP(hipEventRecord(ev[1], st));
-    fsd::launch_bitonic_sort(st, s->pairs.p, s->capacity, s->sort_dirty.p);
+    const bool counting = s->opts.sort_mode == FS_SORT_COUNTING;
+    if (counting) {
+        fsd::launch_counting_sort_pairs(st, s->capacity, P.ncell, s->pairs.p, s->cs.p, s->csort.p, s->counter.p,
+                                        s->slab_counters.p);
+    } else {
+        fsd::launch_bitonic_sort(st, s->pairs.p, s->capacity, s->sort_dirty.p);
+    }
     if (ev) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
                              s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,
-                             s->slab_counters.p);
+                             s->slab_counters.p, counting);
     if (ev) FS_HIP(hipEventRecord(ev[3], st));
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p);
     if (ev) FS_HIP(hipEventRecord(ev[4], st));

@@ -35,7 +35,7 @@ void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots
 void launch_slab_reorder(hipStream_t st, const StepParams& P, uint32_t cap, const u64* pairs, const float2* pos_in,
                          const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s,
                          unsigned char* owned, uint32_t* cs, uint32_t* start_ref, void* work, uint32_t* counter,
-                         uint32_t work_cap, uint32_t* n_live_out);
+                         uint32_t work_cap, uint32_t* n_live_out, bool cs_ready = false);
 void launch_slab_export(hipStream_t st, const StepParams& P, uint32_t cap, const float2* pos, const float2* pred,
                         const float2* vel, const float* rho, const uint32_t* key, void* out);
 void launch_slab_import(hipStream_t st, const StepParams& P, uint32_t n, uint32_t cap, const void* in, float2* pos,
@@ -51,6 +51,8 @@ uint32_t sort_tile_count(uint32_t n);
 
 // FS_SORT_COUNTING (kernels_csort.hip): fills `pairs` (stable order) and the dense table `cs`.
 size_t counting_sort_scratch_words(uint32_t n, uint32_t ncell);
+void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, u64* pairs, uint32_t* cs, uint32_t* scratch,
+                                uint32_t* gap_counter, uint32_t* n_live_out);
 void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, u64* pairs,
                           uint32_t* cs, uint32_t* scratch, uint32_t* gap_counter);
 

@@ -133,6 +133,70 @@ __global__ __launch_bounds__(CS_BLOCK) void k_cs_fixup(uint32_t n, uint32_t ncel
     pairs[lo + rank] = ((u64)kk << 32) | (u64)src;
 }
 
+// ---- slab mode: keys come from the (key<<32 | slot) pairs, DEAD slots are skipped -------------
+__global__ __launch_bounds__(CS_BLOCK) void k_cs_hist_pairs(uint32_t cap, uint32_t ncell, const u64* __restrict__ pairs,
+                                                            uint32_t* __restrict__ key_out, uint32_t* __restrict__ hist,
+                                                            uint32_t* __restrict__ gap_counter) {
+    const uint32_t i = blockIdx.x * CS_BLOCK + threadIdx.x;
+    if (i == 0) *gap_counter = 0;
+    uint32_t key = FS_DEAD_KEY;
+    if (i < cap) { key = (uint32_t)(pairs[i] >> 32); key_out[i] = key; }
+    const bool active = key != FS_DEAD_KEY;
+    const uint32_t k = key < ncell ? key : ncell - 1u;
+    const WaveRun r = wave_run(k, active);
+    if (r.is_head) atomicAdd(&hist[k], r.length);
+}
+
+__global__ __launch_bounds__(CS_BLOCK) void k_cs_scatter_live(uint32_t cap, uint32_t ncell, const uint32_t* __restrict__ key,
+                                                              const uint32_t* __restrict__ cs, uint32_t* __restrict__ cursor,
+                                                              uint32_t* __restrict__ slot_src, uint32_t* __restrict__ n_live_out) {
+    const uint32_t i = blockIdx.x * CS_BLOCK + threadIdx.x;
+    if (i == 0) *n_live_out = cs[ncell];                 // total of the histogram = live particles
+    const uint32_t kk = i < cap ? key[i] : FS_DEAD_KEY;
+    const bool active = kk != FS_DEAD_KEY;
+    const uint32_t k = kk < ncell ? kk : ncell - 1u;
+    const WaveRun r = wave_run(k, active);
+    uint32_t base = 0;
+    if (r.is_head) base = cs[k] + atomicAdd(&cursor[k], r.length);
+    base = __shfl(base, r.head_lane);
+    if (active) slot_src[base + r.offset] = i;
+}
+
+__global__ __launch_bounds__(CS_BLOCK) void k_cs_fixup_live(uint32_t cap, uint32_t ncell, const uint32_t* __restrict__ key,
+                                                            const uint32_t* __restrict__ cs,
+                                                            const uint32_t* __restrict__ slot_src, u64* __restrict__ pairs) {
+    const uint32_t p = blockIdx.x * CS_BLOCK + threadIdx.x;
+    if (p >= cap) return;
+    const uint32_t n_live = cs[ncell];
+    if (p >= n_live) { pairs[p] = ((u64)FS_DEAD_KEY << 32) | (u64)p; return; }
+    const uint32_t src = slot_src[p];
+    const uint32_t kk = key[src];
+    const uint32_t k = kk < ncell ? kk : ncell - 1u;
+    const uint32_t lo = cs[k], hi = cs[k + 1u];
+    uint32_t rank = 0;
+    for (uint32_t q = lo; q < hi; ++q) rank += slot_src[q] < src ? 1u : 0u;
+    pairs[lo + rank] = ((u64)kk << 32) | (u64)src;
+}
+
+void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, u64* pairs, uint32_t* cs, uint32_t* scratch,
+                                uint32_t* gap_counter, uint32_t* n_live_out) {
+    const uint32_t count = ncell + 1u;
+    uint32_t* hist = scratch;
+    uint32_t* cursor = hist + count;
+    uint32_t* key = cursor + ncell;
+    uint32_t* slot_src = key + cap;
+    uint32_t* sums = slot_src + cap;
+    const uint32_t nblocks = (count + CS_TILE - 1) / CS_TILE;
+    const dim3 grid((cap + CS_BLOCK - 1) / CS_BLOCK), block(CS_BLOCK);
+    (void)hipMemsetAsync(hist, 0, ((size_t)count + ncell) * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_cs_hist_pairs, grid, block, 0, st, cap, ncell, pairs, key, hist, gap_counter);
+    hipLaunchKernelGGL(k_cs_scan_reduce, dim3(nblocks), block, 0, st, hist, count, sums);
+    hipLaunchKernelGGL(k_cs_scan_sums, dim3(1), block, 0, st, sums, nblocks);
+    hipLaunchKernelGGL(k_cs_scan_apply, dim3(nblocks), block, 0, st, hist, count, sums, cs);
+    hipLaunchKernelGGL(k_cs_scatter_live, grid, block, 0, st, cap, ncell, key, cs, cursor, slot_src, n_live_out);
+    hipLaunchKernelGGL(k_cs_fixup_live, grid, block, 0, st, cap, ncell, key, cs, slot_src, pairs);
+}
+
 size_t counting_sort_scratch_words(uint32_t n, uint32_t ncell) {
     const size_t nblocks = ((size_t)ncell + 1 + CS_TILE - 1) / CS_TILE;
     // hist (ncell+1) | cursor (ncell) | key (n) | slot_src (n) | block sums

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_unpack(StepParams P, uint32_t
 
 // k_reorder for slab mode: DEAD slots are skipped, the live count and the owned flags are
 // produced here.  `cap` = number of slots sorted.
+template <bool FILL>
 __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_t cap, const u64* __restrict__ pairs,
                                                            const float2* __restrict__ pos_in,
                                                            const float2* __restrict__ vel_in,
@@ -176,8 +177,10 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
     const uint32_t key = (uint32_t)(pr >> 32);
     const uint32_t prev = i ? (uint32_t)(pairs[i - 1] >> 32) : 0u;
     if (key == FS_DEAD_KEY) {
-        if (i == 0) { *n_live_out = 0; fill_cells(cs, 0u, P.ncell + 1u, 0u, work, counter, work_cap); }
-        else if (prev != FS_DEAD_KEY) *n_live_out = i;
+        if (FILL) {   // bitonic path: the live count and the table come from here
+            if (i == 0) { *n_live_out = 0; fill_cells(cs, 0u, P.ncell + 1u, 0u, work, counter, work_cap); }
+            else if (prev != FS_DEAD_KEY) *n_live_out = i;
+        }
         owned[i] = 0;
         return;
     }
@@ -195,16 +198,18 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
     const uint32_t kc = key < P.ncell ? key : P.ncell;
     if (i == 0) {
         if (key < P.ncell) start_ref[key] = 0;
-        fill_cells(cs, 0u, kc + 1u, 0u, work, counter, work_cap);
+        if (FILL) fill_cells(cs, 0u, kc + 1u, 0u, work, counter, work_cap);
     } else if (key != prev) {
         if (key < P.ncell) start_ref[key] = i;
         const uint32_t pc = prev < P.ncell ? prev : P.ncell;
-        fill_cells(cs, pc + 1u, kc + 1u, i, work, counter, work_cap);
+        if (FILL) fill_cells(cs, pc + 1u, kc + 1u, i, work, counter, work_cap);
     }
-    const bool last = (i + 1 == cap) || ((uint32_t)(pairs[i + 1] >> 32) == FS_DEAD_KEY);
-    if (last) {
-        fill_cells(cs, kc + 1u, P.ncell + 1u, i + 1u, work, counter, work_cap);
-        if (i + 1 == cap) *n_live_out = cap;
+    if (FILL) {
+        const bool last = (i + 1 == cap) || ((uint32_t)(pairs[i + 1] >> 32) == FS_DEAD_KEY);
+        if (last) {
+            fill_cells(cs, kc + 1u, P.ncell + 1u, i + 1u, work, counter, work_cap);
+            if (i + 1 == cap) *n_live_out = cap;
+        }
     }
 }
 
@@ -290,8 +295,13 @@ void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots
 void launch_slab_reorder(hipStream_t st, const StepParams& P, uint32_t cap, const u64* pairs, const float2* pos_in,
                          const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s,
                          unsigned char* owned, uint32_t* cs, uint32_t* start_ref, void* work, uint32_t* counter,
-                         uint32_t work_cap, uint32_t* n_live_out) {
-    hipLaunchKernelGGL(k_slab_reorder, dim3(nb(cap)), dim3(SL_BLOCK), 0, st, P, cap, pairs, pos_in, vel_in, pos_s,
+                         uint32_t work_cap, uint32_t* n_live_out, bool cs_ready) {
+    if (cs_ready) {   // counting sort: table and live count already exist
+        hipLaunchKernelGGL(k_slab_reorder<false>, dim3(nb(cap)), dim3(SL_BLOCK), 0, st, P, cap, pairs, pos_in, vel_in,
+                           pos_s, vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out);
+        return;
+    }
+    hipLaunchKernelGGL(k_slab_reorder<true>, dim3(nb(cap)), dim3(SL_BLOCK), 0, st, P, cap, pairs, pos_in, vel_in, pos_s,
                        vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out);
     launch_fill_gaps(st, cs, work, counter, work_cap);
 }

@@ -268,7 +268,8 @@ def bench_main(args, rank, local_rank, world):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "particles": n, "scene": "SURVEY.md §8d dam_break_2d",
-                       "sort": "bitonic", "parallelism": f"{world} column slabs, RCCL p2p halo ({backend})",
+                       "sort": "counting (slab default: per-rank sorts are tolerance-parity by construction)",
+                       "parallelism": f"{world} column slabs, RCCL p2p halo ({backend})",
                        "slab_columns": [bounds[k + 1] - bounds[k] for k in range(world)],
                        "message_bytes": msg_bytes},
             "roofline": {"bound": "hbm", "kernel": "whole step (aggregate over GPUs)", "achieved": round(agg, 1),

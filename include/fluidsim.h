@@ -213,7 +213,7 @@ typedef struct fs_slab_config {
     uint32_t capacity;            /* particle slots of the local array (incl. 2*recv_capacity) */
     uint32_t recv_capacity;       /* records per incoming message */
     uint32_t max_cols;            /* widest owned window this handle must support (re-balancing) */
-    uint32_t reserved;
+    uint32_t sort_mode;           /* 0 = default (counting sort); 1 + fs_sort_mode selects explicitly */
 } fs_slab_config;
 
 typedef struct fs_slab_counters {
