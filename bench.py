@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--workload", default="dam_break_2d_16M", choices=sorted(WORKLOADS))
     ap.add_argument("--sort", default="bitonic", choices=["bitonic", "counting"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra counting-sort measurement")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     args = ap.parse_args()
@@ -147,9 +148,21 @@ def main():
         "host_wall_ms_per_step": round(t_wall / args.steps, 4),
         "roofline": roofline,
     }
+    sim.close()
+    if not is3d and args.sort == "bitonic" and not args.no_alt:
+        # extra (not the headline): the same scene with the O(N) stable counting sort
+        alt = g.FluidSimulation(st, device=local_rank, initial_offset=off, sort_mode=g.FS_SORT_COUNTING)
+        for _ in range(args.warmup):
+            alt.tick(tick)
+        alt.sync()
+        ams = alt.timed_steps(tick, args.steps) / args.steps
+        out["alt_counting_sort"] = {"value": round(n / (ams * 1e-3) / 1e6, 2), "unit": "M particle-steps/s",
+                                    "ms_per_step": round(ams, 4),
+                                    "note": "stable cell sort instead of the reference network; floats equal the headline "
+                                            "path to summation-order tolerance"}
+        alt.close()
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    sim.close()
     print(json.dumps(out), flush=True)
 
 
