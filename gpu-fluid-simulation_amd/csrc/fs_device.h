@@ -96,6 +96,54 @@ __device__ __forceinline__ float rand_f32(uint32_t* st) {
     return __fdiv_rn((float)x, 4294967296.0f);
 }
 
+// ---- block neighbour tiles (shared by the 2D and 3D density / force kernels) ------------------
+// A 256-thread workgroup owns 256 consecutive sorted particles (a strip of cells in one grid
+// row), so the candidates of ALL its lanes for one sweep row form one short contiguous index
+// range.  block_tile_bounds() reduces the per-lane [lo, hi) of three sweep rows to block-wide
+// ranges and says whether they fit an LDS tile of `tile` entries each.
+struct RowRanges { uint32_t lo[3], hi[3]; };
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+
+// Block-wide [min lo, max hi) per sweep row; returns true when all three fit the tile.
+__device__ __forceinline__ bool block_tile_bounds(const RowRanges& R, uint32_t* s_red /*[24]*/, uint32_t* blo,
+                                                  uint32_t* bhi, uint32_t tile) {
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const bool has = R.lo[r] < R.hi[r];
+        const uint32_t mn = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
+        const uint32_t mx = wave_max_u32(has ? R.hi[r] : 0u);
+        if (lane == 0) { s_red[(r * 2) * 4 + w] = mn; s_red[(r * 2 + 1) * 4 + w] = mx; }
+    }
+    __syncthreads();
+    bool fit = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        uint32_t mn = s_red[(r * 2) * 4], mx = s_red[(r * 2 + 1) * 4];
+#pragma unroll
+        for (int k = 1; k < 4 /* waves per 256-thread workgroup */; ++k) {
+            const uint32_t a = s_red[(r * 2) * 4 + k], b = s_red[(r * 2 + 1) * 4 + k];
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        if (mx <= mn) { mn = 0; mx = 0; }
+        blo[r] = mn; bhi[r] = mx;
+        fit = fit && (mx - mn <= tile);
+    }
+    return fit;
+}
+
+
 // ---- dense cell-start table fill (shared by the 2D, slab and 3D reorder kernels) -------------
 // cs[c] = index of the first sorted particle whose key is >= c.  Short gaps are written by the
 // boundary lane; long gaps (empty regions of the domain) go to a worklist drained by k_fill_gaps.

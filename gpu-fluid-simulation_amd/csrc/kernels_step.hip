@@ -124,48 +124,6 @@ __device__ __forceinline__ bool row_range(const StepParams& P, const uint32_t* _
 // straddle a grid-row end (or very sparse ones) exceed the tile and take the global path.
 #define NB_TILE 640          // staged candidates per sweep row
 
-struct RowRanges { uint32_t lo[3], hi[3]; };
-
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
-}
-
-// Block-wide [min lo, max hi) per sweep row; returns true when all three fit the tile.
-__device__ __forceinline__ bool block_tile_bounds(const RowRanges& R, uint32_t* s_red /*[24]*/, uint32_t* blo,
-                                                  uint32_t* bhi) {
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const bool has = R.lo[r] < R.hi[r];
-        const uint32_t mn = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
-        const uint32_t mx = wave_max_u32(has ? R.hi[r] : 0u);
-        if (lane == 0) { s_red[(r * 2) * 4 + w] = mn; s_red[(r * 2 + 1) * 4 + w] = mx; }
-    }
-    __syncthreads();
-    bool fit = true;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        uint32_t mn = s_red[(r * 2) * 4], mx = s_red[(r * 2 + 1) * 4];
-#pragma unroll
-        for (int k = 1; k < FS_BLOCK / 64; ++k) {
-            const uint32_t a = s_red[(r * 2) * 4 + k], b = s_red[(r * 2 + 1) * 4 + k];
-            mn = a < mn ? a : mn;
-            mx = b > mx ? b : mx;
-        }
-        if (mx <= mn) { mn = 0; mx = 0; }
-        blo[r] = mn; bhi[r] = mx;
-        fit = fit && (mx - mn <= NB_TILE);
-    }
-    return fit;
-}
-
 // -------------------------------------------------------------------- density
 __device__ __forceinline__ float density_term(const StepParams& P, float h2, float2 me, float2 q) {
     const float dx = q.x - me.x, dy = q.y - me.y;
@@ -201,7 +159,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
         if (R.hi[r] < R.lo[r]) R.hi[r] = R.lo[r];
     }
     uint32_t blo[3], bhi[3];
-    const bool fit = block_tile_bounds(R, s_red, blo, bhi);
+    const bool fit = block_tile_bounds(R, s_red, blo, bhi, NB_TILE);
     float rho = 0.0f;
     if (fit) {
 #pragma unroll
@@ -411,10 +369,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
         if (R.hi[r] < R.lo[r]) R.hi[r] = R.lo[r];
     }
     uint32_t blo[3], bhi[3];
-    const bool fit = block_tile_bounds(R, s_red, blo, bhi);
-    bool staged = fit;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) staged = staged && (bhi[r] - blo[r] <= NBF_TILE);
+    const bool staged = block_tile_bounds(R, s_red, blo, bhi, NBF_TILE);
     if (staged) {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
