@@ -113,3 +113,21 @@ def test_3d_8m_properties(fs):
     assert np.all(p["grid"][:-1] <= p["grid"][1:])
     assert np.isfinite(p["position"]).all() and np.isfinite(p["velocity"]).all()
     assert np.median(p["density"]) == pytest.approx(1009.8, rel=2e-3)
+
+
+@pytest.mark.gpu
+def test_3d_dense_cluster(fs, orc):
+    """Hot cells in 3D: list flushes and the global fallback of the staged density path."""
+    n = 12 ** 3
+    st, off, tick = fs.dam_break_3d(n)
+    sim = fs.FluidSimulation3D(st, device=0, initial_offset=off)
+    ref = orc.OracleSim3D(st, off)
+    rng = np.random.default_rng(23)
+    p = ref.particles()
+    idx = rng.choice(n, 900, replace=False)
+    p["position"][idx] = rng.uniform(-0.25, 0.25, size=(900, 3)).astype(np.float32) + np.float32([0.3, 0.2, 0.1])
+    p["predicted_position"] = p["position"]
+    ref.set_particles(p); sim.upload_particles(p)
+    for s in range(2):
+        sim.tick(tick); ref.step(tick)
+        _assert_equal3(sim.download_particles(), ref.particles(), f"3d cluster step {s}")

@@ -291,3 +291,31 @@ def test_counting_vs_bitonic_within_tolerance(fs):
     for _ in range(4):
         a.tick(tick); b.tick(tick)
     match_and_compare(b.download_particles(), a.download_particles(), st.smoothing_radius)
+
+
+@pytest.mark.parametrize("sort_mode", ["bitonic", "counting"])
+def test_dense_cluster_exercises_overflow_paths(fs, orc, sort_mode):
+    """3000 of 8192 particles squeezed into ~3x3 cells: hundreds of in-radius neighbours per particle
+    (neighbour-list flushes), candidate ranges longer than the LDS tiles (global fallback path), plus
+    empty space (long cell-table gaps).  Still bit-exact against the oracle."""
+    n = 8192
+    st = fs.SimulationSettings(n, 0.1, 0.2, (40.0, 30.0))
+    tick = fs.default_tick_settings(gravity=(0.0, 9.81))
+    mode = fs.FS_SORT_BITONIC if sort_mode == "bitonic" else fs.FS_SORT_COUNTING
+    sim = fs.FluidSimulation(st, device=0, sort_mode=mode)
+    ref = orc.OracleSim(st)
+    rng = np.random.default_rng(17)
+    p = ref.particles()
+    idx = rng.choice(n, 3000, replace=False)
+    p["position"][idx] = rng.uniform(-0.3, 0.3, size=(3000, 2)).astype(np.float32) + np.float32([5.0, -4.0])
+    p["predicted_position"] = p["position"]
+    p["velocity"] = rng.uniform(-0.5, 0.5, size=(n, 2)).astype(np.float32)
+    ref.set_particles(p); sim.upload_particles(p)
+    for s in range(3):
+        sim.tick(tick)
+        ref.step(tick, stable_sort=(sort_mode == "counting"))
+        got, want = sim.download_particles(), ref.particles()
+        assert_particles_equal(got, want, f"cluster/{sort_mode} step {s}")
+        assert np.array_equal(sim.download_start_indices(), ref.start_indices())
+    cells, cnt = np.unique(want["grid"], return_counts=True)
+    assert cnt.max() > 150          # the scene really has hot cells
