@@ -193,6 +193,17 @@ class FluidSimulation:
         h, w = field.shape[0], field.shape[1]
         _check(self._lib, self._lib.fs_upload_force_field(self._h, field.ctypes.data_as(C.c_void_p), w, h))
 
+    def render_density(self, width, height, world_min=None, world_max=None):
+        """Headless density-splat image (fluid_shader.wgsl:27-102): float32 [height, width, 4] RGBA.
+        Default view = the reference camera: the whole domain, +y down (src/renderer.rs:558-561)."""
+        sx, sy = self.settings.size.x, self.settings.size.y
+        wmin = world_min if world_min is not None else (-sx / 2, -sy / 2)
+        wmax = world_max if world_max is not None else (sx / 2, sy / 2)
+        view = _abi.View(Vec2(float(wmin[0]), float(wmin[1])), Vec2(float(wmax[0]), float(wmax[1])), int(width), int(height))
+        out = np.empty((int(height), int(width), 4), dtype=np.float32)
+        _check(self._lib, self._lib.fs_render_density(self._h, C.byref(view), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def particles_device_ptr(self):
         p = C.c_void_p()
         _check(self._lib, self._lib.fs_particles_device(self._h, C.byref(p)))
@@ -419,6 +430,25 @@ class ResizableBuffer:
             self.close()
         except Exception:
             pass
+
+
+def write_png(path, rgba, background=(0.0, 0.0, 0.0)):
+    """Minimal PNG writer (zlib only): composites straight-alpha RGBA f32 over `background`, 8-bit RGB."""
+    import struct
+    import zlib
+    a = np.clip(rgba[..., 3:4], 0.0, 1.0)
+    rgb = np.clip(rgba[..., :3], 0.0, 1.0) * a + np.asarray(background, dtype=np.float32) * (1.0 - a)
+    img = (np.clip(rgb, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+    h, w = img.shape[:2]
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
 def reference_lattice(settings, offset=(0.0, 0.0)):

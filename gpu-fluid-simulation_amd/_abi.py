@@ -120,6 +120,10 @@ PARTICLE3_DTYPE = np.dtype([("position", "<f4", (3,)), ("predicted_position", "<
 assert PARTICLE3_DTYPE.itemsize == 48
 
 
+class View(C.Structure):
+    _fields_ = [("world_min", Vec2), ("world_max", Vec2), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
 class SlabConfig(C.Structure):
     _fields_ = [
         ("own_lo", C.c_uint32), ("own_hi", C.c_uint32),
@@ -184,6 +188,7 @@ PROTOTYPES = {
     "fs_reference_lattice": (C.c_int, [C.POINTER(Settings), Vec2, _P, C.c_size_t]),
     "fs_sort_schedule": (C.c_size_t, [C.c_uint32, _P, C.c_size_t]),
     "fs_build_uniform": (C.c_int, [C.POINTER(Settings), C.POINTER(TickSettings), C.c_uint32, C.POINTER(Uniform)]),
+    "fs_render_density": (C.c_int, [_P, C.POINTER(View), _P]),
     "fs_profile_enable": (C.c_int, [_P, C.c_int]),
     "fs_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "fs_timed_steps": (C.c_int, [_P, C.POINTER(TickSettings), C.c_uint32, C.POINTER(C.c_double)]),

@@ -541,6 +541,29 @@ fs_status fs_build_uniform(const fs_settings* settings, const fs_tick_settings* 
     return FS_OK;
 }
 
+fs_status fs_render_density(fs_sim* s, const fs_view* view, float* rgba_host) {
+    if (!s || !view || !rgba_host) return fail(FS_ERR_INVALID, "null argument");
+    if (s->slab) return fail(FS_ERR_UNSUPPORTED, "render on a slab handle");
+    if (view->width == 0 || view->height == 0 || (uint64_t)view->width * view->height > (1ull << 28))
+        return fail(FS_ERR_INVALID, "bad image size");
+    if (s->tick == 0) return fail(FS_ERR_INVALID, "render needs at least one fs_step (cell table not built yet)");
+    FS_HIP(hipSetDevice(s->device));
+    const size_t npix = (size_t)view->width * view->height;
+    float4* dimg = nullptr;
+    FS_HIP(hipMalloc((void**)&dimg, npix * sizeof(float4)));
+    const fsd::StepParams P = make_params(*s);
+    // after a step: `pred` = predicted positions of this step, `vel` = updated velocities (what the
+    // reference's fragment shader sees in in_particles at draw time)
+    fsd::launch_render_density(s->stream, P, make_float2(view->world_min.x, view->world_min.y),
+                               make_float2(view->world_max.x, view->world_max.y), view->width, view->height, s->pred.p,
+                               s->vel.p, s->cs.p, s->start_ref.p, s->pairs.p, dimg);
+    hipError_t e = hipMemcpyAsync(rgba_host, dimg, npix * sizeof(float4), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(dimg);
+    if (e != hipSuccess) return fail(FS_ERR_DEVICE, hipGetErrorString(e));
+    return FS_OK;
+}
+
 fs_status fs_profile_enable(fs_sim* s, int enable) {
     if (!s) return fail(FS_ERR_INVALID, "null argument");
     s->profile = enable != 0;

@@ -22,6 +22,9 @@ void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const floa
                        const float* rho, const uint32_t* key, void* out);
 void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, float2* pred, float2* vel, float* rho,
                        uint32_t* key);
+void launch_render_density(hipStream_t st, const StepParams& P, float2 wmin, float2 wmax, uint32_t width,
+                           uint32_t height, const float2* pred, const float2* vel, const uint32_t* cs,
+                           const uint32_t* start_ref, const u64* pairs, float4* out);
 size_t gap_entry_size();
 void launch_fill_gaps(hipStream_t st, uint32_t* cs, const void* work, const uint32_t* counter, uint32_t work_cap);
 

@@ -464,6 +464,70 @@ __global__ __launch_bounds__(FS_BLOCK) void k_import_aos(uint32_t n, const AosPa
     pos[i] = a.position; pred[i] = a.predicted; vel[i] = a.velocity; rho[i] = a.density; key[i] = a.grid;
 }
 
+// ------------------------------------------------------- density-splat image (fluid_shader.wgsl:27-102)
+__device__ __forceinline__ float smoothstep_f(float a, float b, float x) {
+    float t = __fdiv_rn(x - a, b - a);
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+__global__ __launch_bounds__(FS_BLOCK) void k_render_density(StepParams P, float2 wmin, float2 wmax, uint32_t width,
+                                                             uint32_t height, const float2* __restrict__ pred,
+                                                             const float2* __restrict__ vel,
+                                                             const uint32_t* __restrict__ cs,
+                                                             const uint32_t* __restrict__ start_ref,
+                                                             const u64* __restrict__ pairs, float4* __restrict__ out) {
+    const uint32_t pix = blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (pix >= width * height) return;
+    const uint32_t i = pix % width, j = pix / width;
+    float2 pt;
+    pt.x = wmin.x + __fdiv_rn((float)i + 0.5f, (float)width) * (wmax.x - wmin.x);
+    pt.y = wmin.y + __fdiv_rn((float)j + 0.5f, (float)height) * (wmax.y - wmin.y);
+    const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
+    uint32_t cx, cy;
+    xy_local(P, pt, &cx, &cy);
+    float density = 0.0f, vfac = 0.0f;
+    const float denom = P.sqr_radius / 2.0f;                            // fluid_shader.wgsl:66
+    for (int oy = -2; oy < 3; ++oy) {                                   // :39-40 (5x5 cells)
+        const uint32_t y = cy + (uint32_t)oy;
+        if (y >= P.grid_h) continue;
+        const int32_t xl = (int32_t)cx - 2, xh = (int32_t)cx + 3;
+        const uint32_t xlo = xl < 0 ? 0u : (uint32_t)xl;
+        const uint32_t xhi = xh > (int32_t)P.grid_w ? P.grid_w : (uint32_t)xh;
+        if (xlo >= xhi) continue;
+        uint32_t a = cs[y * P.grid_w + xlo];
+        const uint32_t b = cs[y * P.grid_w + xhi];
+        if (a == 0u) a = lo_fix;
+        for (uint32_t k = a; k < b; ++k) {
+            const float2 q = pred[k];
+            const float2 v = vel[k];
+            const float ox = q.x - pt.x, oyv = q.y - pt.y;
+            const float r2 = ox * ox + oyv * oyv;
+            const float contrib = expf(__fdiv_rn(-r2, denom));
+            density += contrib;
+            vfac += contrib * sqrt_rn(v.x * v.x + v.y * v.y);           // :68
+        }
+    }
+    vfac = vfac * 0.01f;                                                // :79-83
+    vfac = __fdiv_rn(logf(1.0f + 5.0f * vfac), logf(1.0f + 5.0f));
+    vfac = fminf(fmaxf(vfac, 0.0f), 1.0f);
+    const float interior = smoothstep_f(0.5f, 1.5f, density);           // :86
+    float edge = smoothstep_f(0.7f, 1.0f, density) - smoothstep_f(1.0f, 1.5f, density);
+    edge = edge * (1.0f + vfac * 2.0f);                                 // :89-90
+    const float br = (0.0f * (1.0f - vfac) + 1.0f * vfac) * interior;   // mix(blue, red, vfac) * interior, :93
+    const float bg = (0.5f * (1.0f - vfac) + 0.0f * vfac) * interior;
+    const float bb = (1.0f * (1.0f - vfac) + 0.0f * vfac) * interior;
+    out[pix] = make_float4(br + edge, bg + edge, bb + edge, fminf(fmaxf(interior, 0.0f), 1.0f));
+}
+
+void launch_render_density(hipStream_t st, const StepParams& P, float2 wmin, float2 wmax, uint32_t width,
+                           uint32_t height, const float2* pred, const float2* vel, const uint32_t* cs,
+                           const uint32_t* start_ref, const u64* pairs, float4* out) {
+    const uint32_t npix = width * height;
+    hipLaunchKernelGGL(k_render_density, dim3((npix + FS_BLOCK - 1) / FS_BLOCK), dim3(FS_BLOCK), 0, st, P, wmin, wmax,
+                       width, height, pred, vel, cs, start_ref, pairs, out);
+}
+
 // ------------------------------------------------------------------ launchers
 static inline uint32_t nblk(uint32_t n) { return (n + FS_BLOCK - 1) / FS_BLOCK; }
 

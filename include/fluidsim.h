@@ -190,6 +190,19 @@ size_t fs_sort_schedule(uint32_t particle_count, fs_sort_step* dst, size_t cap);
 fs_status fs_build_uniform(const fs_settings* settings, const fs_tick_settings* tick,
                            uint32_t tick_count, fs_uniform* out);
 
+/* ------------------------------------------------- renderer hand-off */
+/* Headless version of the reference's density-splat fragment shader (fluid_shader.wgsl:27-102):
+ * per pixel a 5x5-cell walk over the cell-sorted particles, Gaussian splat of density and
+ * speed, colour ramp.  The reference draws a full-screen quad through an orthographic
+ * projection over the whole domain with +y down (src/renderer.rs:558-561); `fs_view` is that
+ * mapping made explicit: pixel (i, j) samples world_min + ((i+0.5)/width, (j+0.5)/height) *
+ * (world_max - world_min).  Output: width*height RGBA f32 (straight alpha), host memory. */
+typedef struct fs_view {
+    fs_vec2 world_min, world_max;
+    uint32_t width, height;
+} fs_view;
+fs_status fs_render_density(fs_sim* sim, const fs_view* view, float* rgba_host);
+
 /* -------------------------------------------------------------- profiling */
 /* Per-pass device time measured with hipEvents on the simulation's stream. */
 enum { FS_PASS_PREDICT_KEY = 0, FS_PASS_SORT = 1, FS_PASS_REORDER = 2, FS_PASS_DENSITY = 3,

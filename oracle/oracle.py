@@ -41,6 +41,7 @@ def lib():
         L.orc_density.argtypes = [P, C.c_int]
         L.orc_step.argtypes = [P, P]
         L.orc_step_stable.argtypes = [P, P]
+        L.orc_render.argtypes = [P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, P]
         L.orc_tick.restype = C.c_uint32
         L.orc_tick.argtypes = [P]
         L.orc_count.restype = C.c_uint32
@@ -165,6 +166,12 @@ class OracleSim:
     def cell_starts(self): self.L.orc_cell_starts(self.h)
     def density(self, reach=1): self.L.orc_density(self.h, int(reach))
     def move(self): self.L.orc_move(self.h)
+
+    def render(self, width, height, world_min, world_max):
+        out = np.empty((height, width, 4), dtype=np.float32)
+        self.L.orc_render(self.h, float(world_min[0]), float(world_min[1]), float(world_max[0]), float(world_max[1]),
+                          int(width), int(height), out.ctypes.data)
+        return out
 
     @property
     def tick_count(self):

@@ -512,6 +512,47 @@ fs_vec2* orc_texture(orc_sim* h) { return ((OrcSim*)h)->texture.data(); }
 void orc_uniform(const orc_sim* h, fs_uniform* out) { *out = ((const OrcSim*)h)->u; }
 float orc_poly6_norm(const orc_sim* h) { return ((const OrcSim*)h)->poly6_norm; }
 
+/* fluid_shader.wgsl:27-102 — density-splat fragment shader on the oracle's state, walking
+ * start_indices exactly like the shader.  View mapping: see include/fluidsim.h fs_view. */
+void orc_render(orc_sim* h, float wminx, float wminy, float wmaxx, float wmaxy, uint32_t width, uint32_t height, float* rgba) {
+    OrcSim& s = *(OrcSim*)h;
+    const fs_uniform& u = s.u;
+    auto smooth = [](float a, float b, float x) { float t = (x - a) / (b - a); t = std::fmin(std::fmax(t, 0.0f), 1.0f); return t * t * (3.0f - 2.0f * t); };
+    for (uint32_t j = 0; j < height; ++j)
+        for (uint32_t i = 0; i < width; ++i) {
+            fs_vec2 pt;
+            pt.x = wminx + (((float)i + 0.5f) / (float)width) * (wmaxx - wminx);
+            pt.y = wminy + (((float)j + 0.5f) / (float)height) * (wmaxy - wminy);
+            uint32_t cxu, cyu;
+            xy_of_point(u, pt, &cxu, &cyu);
+            const int32_t cx = (int32_t)cxu, cy = (int32_t)cyu;
+            float density = 0.0f, vfac = 0.0f;
+            for (int oy = -2; oy < 3; ++oy)
+                for (int ox = -2; ox < 3; ++ox) {
+                    const uint32_t x = (uint32_t)(cx + ox), y = (uint32_t)(cy + oy);
+                    if (x >= u.grid_w || y >= u.grid_h) continue;      // wrapped ids alias empty cells / OOB: nothing
+                    walk_cell(s, s.p, grid_pos_to_id(u, x, y), [&](uint32_t, const fs_particle& nb) {
+                        const float dx = nb.predicted_position.x - pt.x, dy = nb.predicted_position.y - pt.y;
+                        const float r2 = dx * dx + dy * dy;
+                        const float contrib = std::exp(-r2 / (u.sqr_radius / 2.0f));
+                        density += contrib;
+                        vfac += contrib * std::sqrt(nb.velocity.x * nb.velocity.x + nb.velocity.y * nb.velocity.y);
+                    });
+                }
+            vfac = vfac * 0.01f;
+            vfac = std::log(1.0f + 5.0f * vfac) / std::log(1.0f + 5.0f);
+            vfac = std::fmin(std::fmax(vfac, 0.0f), 1.0f);
+            const float interior = smooth(0.5f, 1.5f, density);
+            float edge = smooth(0.7f, 1.0f, density) - smooth(1.0f, 1.5f, density);
+            edge = edge * (1.0f + vfac * 2.0f);
+            float* o = rgba + 4 * ((size_t)j * width + i);
+            o[0] = (0.0f * (1.0f - vfac) + 1.0f * vfac) * interior + edge;
+            o[1] = (0.5f * (1.0f - vfac) + 0.0f * vfac) * interior + edge;
+            o[2] = (1.0f * (1.0f - vfac) + 0.0f * vfac) * interior + edge;
+            o[3] = std::fmin(std::fmax(interior, 0.0f), 1.0f);
+        }
+}
+
 /* Pure helpers. */
 void orc_lattice(const fs_settings* st, float off_x, float off_y, fs_particle* dst, size_t n) {
     lattice(*st, fs_vec2{off_x, off_y}, dst, n);
