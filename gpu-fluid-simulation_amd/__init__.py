@@ -193,6 +193,16 @@ class FluidSimulation:
         h, w = field.shape[0], field.shape[1]
         _check(self._lib, self._lib.fs_upload_force_field(self._h, field.ctypes.data_as(C.c_void_p), w, h))
 
+    def set_obstacle_image(self, image, want_field=False):
+        """Obstacle mask (u8 [h, w], > 128 = obstacle) -> push-out field written into the simulation
+        (generate_smooth_gradient_field + the renderer's write_buffer: src/main.rs:403-515, renderer.rs:497-502)."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = image.shape
+        out = np.empty((h, w, 2), dtype=np.float32) if want_field else None
+        _check(self._lib, self._lib.fs_generate_force_field(self._h, 0, image.ctypes.data_as(C.c_void_p), w, h,
+                                                            out.ctypes.data_as(C.c_void_p) if want_field else None))
+        return out
+
     def render_density(self, width, height, world_min=None, world_max=None):
         """Headless density-splat image (fluid_shader.wgsl:27-102): float32 [height, width, 4] RGBA.
         Default view = the reference camera: the whole domain, +y down (src/renderer.rs:558-561)."""
@@ -430,6 +440,17 @@ class ResizableBuffer:
             self.close()
         except Exception:
             pass
+
+
+def generate_force_field(image, device=0):
+    """Standalone generate_smooth_gradient_field (src/main.rs:403-515) on the GPU: u8 [h, w] -> f32 [h, w, 2]."""
+    lib = load_library()
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = image.shape
+    out = np.empty((h, w, 2), dtype=np.float32)
+    _check(lib, lib.fs_generate_force_field(None, int(device), image.ctypes.data_as(C.c_void_p), w, h,
+                                            out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def write_png(path, rgba, background=(0.0, 0.0, 0.0)):

@@ -188,6 +188,7 @@ PROTOTYPES = {
     "fs_reference_lattice": (C.c_int, [C.POINTER(Settings), Vec2, _P, C.c_size_t]),
     "fs_sort_schedule": (C.c_size_t, [C.c_uint32, _P, C.c_size_t]),
     "fs_build_uniform": (C.c_int, [C.POINTER(Settings), C.POINTER(TickSettings), C.c_uint32, C.POINTER(Uniform)]),
+    "fs_generate_force_field": (C.c_int, [_P, C.c_int, _P, C.c_uint32, C.c_uint32, _P]),
     "fs_render_density": (C.c_int, [_P, C.POINTER(View), _P]),
     "fs_profile_enable": (C.c_int, [_P, C.c_int]),
     "fs_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),

@@ -541,6 +541,37 @@ fs_status fs_build_uniform(const fs_settings* settings, const fs_tick_settings* 
     return FS_OK;
 }
 
+fs_status fs_generate_force_field(fs_sim* s, int device, const uint8_t* image, uint32_t w, uint32_t h,
+                                  fs_vec2* field_host) {
+    if (!image || w == 0 || h == 0) return fail(FS_ERR_INVALID, "null/empty image");
+    if (h > 1024 || w >= 65536) return fail(FS_ERR_UNSUPPORTED, "image larger than 65535 x 1024");
+    if (s) {
+        if (s->slab) return fail(FS_ERR_UNSUPPORTED, "force field on a slab handle");
+        if (w != s->settings.texture_size.x || h != s->settings.texture_size.y)
+            return fail(FS_ERR_INVALID, "image dimensions differ from settings.texture_size");
+        device = s->device;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(FS_ERR_DEVICE, "no HIP device: the engine has no CPU fallback");
+    FS_HIP(hipSetDevice(device));
+    const size_t npix = (size_t)w * h;
+    unsigned char* dimg = nullptr; float* ddist = nullptr; uint32_t* dnear = nullptr; float2* dfield = nullptr;
+    hipStream_t st = s ? s->stream : nullptr;
+    hipError_t e = hipMalloc((void**)&dimg, npix);
+    if (e == hipSuccess) e = hipMalloc((void**)&ddist, npix * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&dnear, npix * sizeof(uint32_t));
+    if (e == hipSuccess && !s) e = hipMalloc((void**)&dfield, npix * sizeof(float2));
+    float2* out = s ? s->tex.p : dfield;
+    if (e == hipSuccess) e = hipMemcpyAsync(dimg, image, npix, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) { fsd::launch_gradient_field(st, dimg, w, h, ddist, dnear, out); e = hipGetLastError(); }
+    if (e == hipSuccess && field_host) e = hipMemcpyAsync(field_host, out, npix * sizeof(float2), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dimg); (void)hipFree(ddist); (void)hipFree(dnear); (void)hipFree(dfield);
+    if (e != hipSuccess) return fail(FS_ERR_DEVICE, hipGetErrorString(e));
+    return FS_OK;
+}
+
 fs_status fs_render_density(fs_sim* s, const fs_view* view, float* rgba_host) {
     if (!s || !view || !rgba_host) return fail(FS_ERR_INVALID, "null argument");
     if (s->slab) return fail(FS_ERR_UNSUPPORTED, "render on a slab handle");

@@ -25,6 +25,9 @@ void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, 
 void launch_render_density(hipStream_t st, const StepParams& P, float2 wmin, float2 wmax, uint32_t width,
                            uint32_t height, const float2* pred, const float2* vel, const uint32_t* cs,
                            const uint32_t* start_ref, const u64* pairs, float4* out);
+// Obstacle push-out field (kernels_field.hip); h <= 1024, w < 65536.
+void launch_gradient_field(hipStream_t st, const unsigned char* image, uint32_t w, uint32_t h, float* dist,
+                           uint32_t* nearest, float2* field);
 size_t gap_entry_size();
 void launch_fill_gaps(hipStream_t st, uint32_t* cs, const void* work, const uint32_t* counter, uint32_t work_cap);
 

@@ -190,6 +190,16 @@ size_t fs_sort_schedule(uint32_t particle_count, fs_sort_step* dst, size_t cap);
 fs_status fs_build_uniform(const fs_settings* settings, const fs_tick_settings* tick,
                            uint32_t tick_count, fs_uniform* out);
 
+/* ------------------------------------------- obstacle field producer */
+/* generate_smooth_gradient_field (src/main.rs:403-515): u8 mask (> 128 = obstacle source; none ->
+ * the image border) -> per-pixel vector to the nearest source, by the reference's two-pass raster
+ * propagation, reproduced exactly.  `field_host` may be NULL; with `sim` the result is also
+ * written straight into the simulation's force field (the renderer's write_buffer,
+ * src/renderer.rs:497-502), in which case (w, h) must equal settings.texture_size.  sim may be
+ * NULL (then `device` selects the GPU).  Limits: h <= 1024, w < 65536. */
+fs_status fs_generate_force_field(fs_sim* sim, int device, const uint8_t* image, uint32_t w, uint32_t h,
+                                  fs_vec2* field_host);
+
 /* ------------------------------------------------- renderer hand-off */
 /* Headless version of the reference's density-splat fragment shader (fluid_shader.wgsl:27-102):
  * per pixel a 5x5-cell walk over the cell-sorted particles, Gaussian splat of density and

@@ -41,6 +41,7 @@ def lib():
         L.orc_density.argtypes = [P, C.c_int]
         L.orc_step.argtypes = [P, P]
         L.orc_step_stable.argtypes = [P, P]
+        L.orc_gradient_field.argtypes = [P, C.c_uint32, C.c_uint32, P]
         L.orc_render.argtypes = [P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, P]
         L.orc_tick.restype = C.c_uint32
         L.orc_tick.argtypes = [P]
@@ -215,6 +216,15 @@ class OracleSim:
         out = (C.c_char * 120)()
         self.L.orc_uniform(self.h, C.addressof(out))
         return bytes(out)
+
+
+def gradient_field(image):
+    """generate_smooth_gradient_field (src/main.rs:403-515) on the CPU: u8 [h, w] -> f32 [h, w, 2]."""
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = image.shape
+    out = np.empty((h, w, 2), dtype=np.float32)
+    lib().orc_gradient_field(image.ctypes.data, w, h, out.ctypes.data)
+    return out
 
 
 def bitonic_keys(keys):

@@ -553,6 +553,39 @@ void orc_render(orc_sim* h, float wminx, float wminy, float wmaxx, float wmaxy, 
         }
 }
 
+/* src/main.rs:403-515 — generate_smooth_gradient_field, restated line by line. */
+void orc_gradient_field(const uint8_t* img, uint32_t width, uint32_t height, fs_vec2* out) {
+    const size_t W = width, H = height;
+    std::vector<float> dist(W * H, 3.40282347e+38f);                    // f32::MAX, :408
+    std::vector<uint32_t> nx_(W * H, 0), ny_(W * H, 0);                 // nearest, :410
+    bool has_white = false;
+    for (size_t y = 0; y < H; ++y)                                      // :413-422
+        for (size_t x = 0; x < W; ++x)
+            if (img[y * W + x] > 128) { dist[y * W + x] = 0.0f; nx_[y * W + x] = (uint32_t)x; ny_[y * W + x] = (uint32_t)y; has_white = true; }
+    if (!has_white)                                                     // :426-438
+        for (size_t y = 0; y < H; ++y)
+            for (size_t x = 0; x < W; ++x)
+                if (y == H - 1 || y == 0 || x == W - 1 || x == 0) { dist[y * W + x] = 0.0f; nx_[y * W + x] = (uint32_t)x; ny_[y * W + x] = (uint32_t)y; }
+    auto sq = [](size_t x1, size_t y1, size_t x2, size_t y2) { const float dx = (float)x1 - (float)x2, dy = (float)y1 - (float)y2; return dx * dx + dy * dy; };
+    auto relax = [&](size_t x, size_t y, size_t nx, size_t ny) {
+        if (nx < W && ny < H) {                                         // usize wrap-around makes -1 huge
+            const uint32_t cx = nx_[ny * W + nx], cy = ny_[ny * W + nx];
+            const float cd = sq(x, y, cx, cy);
+            if (cd < dist[y * W + x]) { dist[y * W + x] = cd; nx_[y * W + x] = cx; ny_[y * W + x] = cy; }
+        }
+    };
+    for (size_t y = 0; y < H; ++y)                                      // forward pass, :447-468
+        for (size_t x = 0; x < W; ++x) { relax(x, y, x - 1, y); relax(x, y, x - 1, y - 1); relax(x, y, x, y - 1); relax(x, y, x + 1, y - 1); }
+    for (size_t y = H; y-- > 0;)                                        // backward pass, :470-491
+        for (size_t x = W; x-- > 0;) { relax(x, y, x + 1, y); relax(x, y, x + 1, y + 1); relax(x, y, x, y + 1); relax(x, y, x - 1, y + 1); }
+    for (size_t y = 0; y < H; ++y)                                      // :496-511
+        for (size_t x = 0; x < W; ++x) {
+            const float dx = (float)x - (float)nx_[y * W + x], dy = (float)y - (float)ny_[y * W + x];
+            const float len = std::sqrt(dx * dx + dy * dy);
+            out[y * W + x] = fs_vec2{-(len > 1e-6f ? dx : 0.0f), -(len > 1e-6f ? dy : 0.0f)};
+        }
+}
+
 /* Pure helpers. */
 void orc_lattice(const fs_settings* st, float off_x, float off_y, fs_particle* dst, size_t n) {
     lattice(*st, fs_vec2{off_x, off_y}, dst, n);
