@@ -150,17 +150,24 @@ def main():
     }
     sim.close()
     if not is3d and args.sort == "bitonic" and not args.no_alt:
-        # extra (not the headline): the same scene with the O(N) stable counting sort
-        alt = g.FluidSimulation(st, device=local_rank, initial_offset=off, sort_mode=g.FS_SORT_COUNTING)
-        for _ in range(args.warmup):
-            alt.tick(tick)
-        alt.sync()
-        ams = alt.timed_steps(tick, args.steps) / args.steps
-        out["alt_counting_sort"] = {"value": round(n / (ams * 1e-3) / 1e6, 2), "unit": "M particle-steps/s",
-                                    "ms_per_step": round(ams, 4),
-                                    "note": "stable cell sort instead of the reference network; floats equal the headline "
-                                            "path to summation-order tolerance"}
-        alt.close()
+        # extras (NOT the headline): the same scene and protocol in the engine's opt-in modes
+        def alt_run(**kw):
+            a = g.FluidSimulation(st, device=local_rank, initial_offset=off, **kw)
+            for _ in range(args.warmup):
+                a.tick(tick)
+            a.sync()
+            t = a.timed_steps(tick, args.steps) / args.steps
+            a.close()
+            return {"value": round(n / (t * 1e-3) / 1e6, 2), "unit": "M particle-steps/s", "ms_per_step": round(t, 4)}
+        out["alt_modes"] = {
+            "counting_sort": dict(alt_run(sort_mode=g.FS_SORT_COUNTING),
+                                  note="stable O(N) cell sort instead of the reference network (SURVEY 8f-1); floats equal "
+                                       "the headline path to summation-order tolerance"),
+            "wgsl_ulp_math": dict(alt_run(math_mode=g.FS_MATH_WGSL_ULP),
+                                  note="native rcp/sqrt in the force pass (<= ~1.5 ulp, inside WGSL's 2.5-ULP division "
+                                       "contract for the reference shaders); not bit-exact vs the IEEE oracle"),
+            "counting_sort+wgsl_ulp_math": alt_run(sort_mode=g.FS_SORT_COUNTING, math_mode=g.FS_MATH_WGSL_ULP),
+        }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)

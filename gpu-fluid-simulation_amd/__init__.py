@@ -16,6 +16,8 @@ import numpy as np
 
 from . import _abi
 from ._abi import (  # noqa: F401
+    FS_MATH_IEEE,
+    FS_MATH_WGSL_ULP,
     FS_SORT_BITONIC,
     FS_SORT_COUNTING,
     PARTICLE3_DTYPE,
@@ -94,7 +96,7 @@ class FluidSimulation:
     """FluidSimulation (src/simulation.rs:10-37) on one MI355X, driven through the C ABI."""
 
     def __init__(self, settings, device=0, sort_mode=FS_SORT_BITONIC, ref_quirks=True, initial_offset=(0.0, 0.0),
-                 capacity=0):
+                 capacity=0, math_mode=FS_MATH_IEEE):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.settings = settings
@@ -103,6 +105,7 @@ class FluidSimulation:
         opts.device = int(device)
         opts.sort_mode = int(sort_mode)
         opts.ref_quirks = 1 if ref_quirks else 0
+        opts.math_mode = int(math_mode)
         opts.initial_offset = Vec2(float(initial_offset[0]), float(initial_offset[1]))
         opts.capacity = int(capacity)
         _check(self._lib, self._lib.fs_create_ex(C.byref(settings), C.byref(opts), C.byref(self._h)))

@@ -94,7 +94,7 @@ class Options(C.Structure):
         ("device", C.c_int32),
         ("sort_mode", C.c_int32),
         ("ref_quirks", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("math_mode", C.c_int32),
         ("initial_offset", Vec2),
         ("capacity", C.c_uint32),
         ("reserved1", C.c_uint32),
@@ -161,6 +161,8 @@ FS_ERR_COMM = 5
 
 FS_SORT_BITONIC = 0
 FS_SORT_COUNTING = 1
+FS_MATH_IEEE = 0
+FS_MATH_WGSL_ULP = 1
 
 PASS_NAMES = ("predict_key", "sort", "reorder", "density", "force")
 

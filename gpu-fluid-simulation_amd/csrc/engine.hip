@@ -232,6 +232,7 @@ fsd::StepParams make_params(const fs_sim& s) {
     P.tex_w_u = s.settings.texture_size.x;   // u32(u.texture_size.x), compute.wgsl:129
     P.tex_len = (uint32_t)s.tex.n;
     P.ref_quirks = s.opts.ref_quirks;
+    P.fast_math = s.opts.math_mode == FS_MATH_WGSL_ULP ? 1 : 0;
     P.col_origin = 0;
     P.own_lo = 0; P.own_hi = s.grid_w;
     P.grid_w_global = s.grid_w;
@@ -343,6 +344,8 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     if (!settings_valid(*settings, &why)) return fail(FS_ERR_INVALID, why);
     if (opts->sort_mode != FS_SORT_BITONIC && opts->sort_mode != FS_SORT_COUNTING)
         return fail(FS_ERR_INVALID, "unknown sort_mode");
+    if (opts->math_mode != FS_MATH_IEEE && opts->math_mode != FS_MATH_WGSL_ULP)
+        return fail(FS_ERR_INVALID, "unknown math_mode");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(FS_ERR_DEVICE, "no HIP device: the engine has no CPU fallback");

@@ -34,6 +34,7 @@ struct StepParams {
     float tex_w, tex_h;
     uint32_t tex_w_u, tex_len;
     int32_t ref_quirks;
+    int32_t fast_math;         // FS_MATH_WGSL_ULP: native rcp/sqrt in the force pass (not bit-exact)
     // --- slab (multi-GPU) mode: the local grid is a window of global cell columns -------------
     int32_t col_origin;        // global column of local column 0 (0 on a single GPU)
     uint32_t own_lo, own_hi;   // owned window [own_lo, own_hi) in GLOBAL columns

@@ -210,41 +210,52 @@ struct ForceTerms { float px, py, vx, vy; };
 
 // One in-radius neighbour: pressure (compute.wgsl:207-223) and viscosity (:283-288) terms.
 // `seed` only advances on the coincident-particle path (dst == 0, compute.wgsl:211-212).
+// FAST (fs_options.math_mode = FS_MATH_WGSL_ULP): `/` becomes n * v_rcp_f32(d) (<= ~1.5 ulp) and sqrt
+// the native v_sqrt_f32 (1 ulp) — inside WGSL's own accuracy contract for the reference shaders (f32
+// division 2.5 ULP, sqrt via inverseSqrt 2 ULP), but no longer bit-identical to the IEEE oracle.
+template <bool FAST> __device__ __forceinline__ float fs_div(float n, float d) {
+    return FAST ? n * __builtin_amdgcn_rcpf(d) : __fdiv_rn(n, d);
+}
+template <bool FAST> __device__ __forceinline__ float fs_sqrt(float x) {
+    return FAST ? __builtin_amdgcn_sqrtf(x) : sqrt_rn(x);
+}
+
+template <bool FAST>
 __device__ __forceinline__ ForceTerms force_terms(const StepParams& P, const float2 me, const float2 mv,
                                                   float pressure, const float2 q, const float2 nv, float nrho,
                                                   uint32_t& seed) {
     const float h = P.h;
     const float ox = q.x - me.x, oyv = q.y - me.y;
     const float r2 = ox * ox + oyv * oyv;
-    const float dst = sqrt_rn(r2);                                      // compute.wgsl:207,283
+    const float dst = fs_sqrt<FAST>(r2);                                // compute.wgsl:207,283
     float dx, dy;
     if (dst == 0.0f) {                                                  // :211-212
         const float rx = rand_f32(&seed);
         const float ry = rand_f32(&seed);
-        const float len = sqrt_rn(rx * rx + ry * ry);
-        dx = __fdiv_rn(rx, len);
-        dy = __fdiv_rn(ry, len);
+        const float len = fs_sqrt<FAST>(rx * rx + ry * ry);
+        dx = fs_div<FAST>(rx, len);
+        dy = fs_div<FAST>(ry, len);
     } else {
-        dx = __fdiv_rn(ox, dst);
-        dy = __fdiv_rn(oyv, dst);
+        dx = fs_div<FAST>(ox, dst);
+        dy = fs_div<FAST>(oyv, dst);
     }
     const float npress = P.pressure_k * (nrho - P.rest_density);
     const float kern = (dst <= h) ? (-(h - dst)) * P.spiky : 0.0f;      // funcs.wgsl:101-109
     const float shared = (pressure + npress) * 0.5f;
     ForceTerms T;
-    T.px = __fdiv_rn(dx * kern * shared, nrho);                         // compute.wgsl:223
-    T.py = __fdiv_rn(dy * kern * shared, nrho);
+    T.px = fs_div<FAST>(dx * kern * shared, nrho);                         // compute.wgsl:223
+    T.py = fs_div<FAST>(dy * kern * shared, nrho);
     float kv = 0.0f;                                                    // funcs.wgsl:112-123
     if (dst <= h) {
         if (dst == 0.0f) {
             kv = P.visc_k;
         } else {
-            kv = P.visc_k * ((__fdiv_rn(-(dst * dst * dst), 2.0f * h * h * h)) + (__fdiv_rn(dst * dst, h * h)) +
-                             (__fdiv_rn(h, 2.0f * dst)) - 1.0f);
+            kv = P.visc_k * ((fs_div<FAST>(-(dst * dst * dst), 2.0f * h * h * h)) + (fs_div<FAST>(dst * dst, h * h)) +
+                             (fs_div<FAST>(h, 2.0f * dst)) - 1.0f);
         }
     }
-    T.vx = __fdiv_rn(nv.x - mv.x, nrho) * kv;                           // compute.wgsl:288
-    T.vy = __fdiv_rn(nv.y - mv.y, nrho) * kv;
+    T.vx = fs_div<FAST>(nv.x - mv.x, nrho) * kv;                           // compute.wgsl:288
+    T.vy = fs_div<FAST>(nv.y - mv.y, nrho) * kv;
     return T;
 }
 
@@ -255,7 +266,7 @@ __device__ __forceinline__ ForceTerms force_terms(const StepParams& P, const flo
                              // few in-radius neighbours are gathered in the heavy phase (staging them too cost
                              // occupancy and measured slower: the kernel is issue-bound, not latency-bound)
 
-template <bool STAGED>
+template <bool STAGED, bool FAST>
 __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges& R, const uint32_t* blo,
                                             uint32_t ii, const float2 me, const float2 mv, float pressure,
                                             const float2* __restrict__ pred, const float2* __restrict__ vel_s,
@@ -317,9 +328,9 @@ __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges
                         }
                         const float2 v0 = vel_s[g0], v1 = vel_s[g1];
                         const float d0 = rho[g0], d1 = rho[g1];
-                        const ForceTerms T0 = force_terms(P, me, mv, pressure, q0, v0, d0, A.seed);
+                        const ForceTerms T0 = force_terms<FAST>(P, me, mv, pressure, q0, v0, d0, A.seed);
                         uint32_t seed1 = A.seed;
-                        const ForceTerms T1 = force_terms(P, me, mv, pressure, q1, v1, d1, seed1);
+                        const ForceTerms T1 = force_terms<FAST>(P, me, mv, pressure, q1, v1, d1, seed1);
                         A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
                         if (two) { A.fpx += T1.px; A.fpy += T1.py; A.fvx += T1.vx; A.fvy += T1.vy; A.seed = seed1; }
                     }
@@ -331,6 +342,7 @@ __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges
     }
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* __restrict__ pos_s,
                                                     const float2* __restrict__ vel_s,
                                                     const float2* __restrict__ pred, const float* __restrict__ rho,
@@ -377,9 +389,9 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
                 s_pred[r][j] = pred[blo[r] + j];
             }
         __syncthreads();
-        force_sweep<true>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho, s_pred, s_list, A);
+        force_sweep<true, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho, s_pred, s_list, A);
     } else {
-        force_sweep<false>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho, s_pred, s_list, A);
+        force_sweep<false, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho, s_pred, s_list, A);
     }
     if (!live) return;
     const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
@@ -557,8 +569,12 @@ void launch_density(hipStream_t st, const StepParams& P, const float2* pred, con
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
                   const float* rho, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out) {
-    hipLaunchKernelGGL(k_force, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho, cs, start_ref,
-                       pairs, tex, pos_out, vel_out);
+    if (P.fast_math)
+        hipLaunchKernelGGL(k_force<true>, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho, cs,
+                           start_ref, pairs, tex, pos_out, vel_out);
+    else
+        hipLaunchKernelGGL(k_force<false>, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho, cs,
+                           start_ref, pairs, tex, pos_out, vel_out);
 }
 
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,

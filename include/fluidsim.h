@@ -123,11 +123,17 @@ typedef enum fs_sort_mode {
     FS_SORT_COUNTING = 1   /* O(N) cell counting sort; stable within a cell */
 } fs_sort_mode;
 
+typedef enum fs_math_mode {
+    FS_MATH_IEEE = 0,      /* correctly rounded / and sqrt, no contraction: bit-identical to the CPU oracle */
+    FS_MATH_WGSL_ULP = 1   /* native rcp / sqrt in the force pass (<= ~1.5 ulp): within WGSL's own accuracy
+                              contract for the reference shaders (division 2.5 ULP, sqrt 2 ULP), not bit-exact */
+} fs_math_mode;
+
 typedef struct fs_options {
     int32_t device;            /* HIP device ordinal */
     int32_t sort_mode;         /* fs_sort_mode */
     int32_t ref_quirks;        /* 1 = reproduce compute.wgsl:49-55 stale cell-start behaviour */
-    int32_t reserved0;
+    int32_t math_mode;         /* fs_math_mode (default FS_MATH_IEEE) */
     fs_vec2 initial_offset;    /* translation added to the reference lattice (dam-break scene) */
     uint32_t capacity;         /* particle slots to allocate (0 = particle_count); multi-GPU slabs */
     uint32_t reserved1;

@@ -319,3 +319,30 @@ def test_dense_cluster_exercises_overflow_paths(fs, orc, sort_mode):
         assert np.array_equal(sim.download_start_indices(), ref.start_indices())
     cells, cnt = np.unique(want["grid"], return_counts=True)
     assert cnt.max() > 150          # the scene really has hot cells
+
+
+def test_wgsl_ulp_math_mode_within_tolerance(fs, orc):
+    """FS_MATH_WGSL_ULP (native rcp/sqrt in the force pass) is not bit-exact; it must stay within the
+    stated tolerance of the IEEE oracle: one step from identical state — keys and density exact (density
+    has no division), velocity rtol 1e-5 / position atol 1e-4*h; a few steps — matched."""
+    from tests.slab_oracle import match_and_compare
+    st, off, tick = fs.dam_break_2d(16384)
+    sim = fs.FluidSimulation(st, device=0, initial_offset=off, math_mode=fs.FS_MATH_WGSL_ULP)
+    ref = orc.OracleSim(st, off)
+    rng = np.random.default_rng(4)
+    p = ref.particles()
+    p["position"] += rng.uniform(-0.02, 0.02, size=p["position"].shape).astype(np.float32)
+    p["predicted_position"] = p["position"]
+    p["velocity"] = rng.uniform(-1, 1, size=p["velocity"].shape).astype(np.float32)
+    ref.set_particles(p); sim.upload_particles(p)
+    sim.tick(tick); ref.step(tick)
+    got, want = sim.download_particles(), ref.particles()
+    assert np.array_equal(got["grid"], want["grid"])
+    assert np.array_equal(got["density"].view(np.uint32), want["density"].view(np.uint32))
+    assert np.array_equal(got["predicted_position"].view(np.uint32), want["predicted_position"].view(np.uint32))
+    np.testing.assert_allclose(got["velocity"], want["velocity"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(got["position"], want["position"], rtol=0, atol=1e-4 * 0.2)
+    assert not np.array_equal(got["velocity"].view(np.uint32), want["velocity"].view(np.uint32))   # really a different mode
+    for _ in range(4):
+        sim.tick(tick); ref.step(tick)
+    match_and_compare(sim.download_particles(), ref.particles(), st.smoothing_radius)
