@@ -186,8 +186,11 @@ class SlabDriver:
 
 
 # ----------------------------------------------------------------------------- setup helpers
-def slab_capacities(n_total, world, grid_h, headroom=1.3):
-    recv = max(4096, 6 * grid_h * 10)                 # migrants + 2 ghost columns, compressed fluid
+def slab_capacities(n_total, world, grid_h, headroom=1.25):
+    """(capacity, recv_capacity).  A message carries 2 ghost columns + migrants: ~2 * grid_h * 4 records at
+    lattice density; 3 * grid_h * 8 leaves ~3x headroom (the device counters flag an overflow).  Smaller
+    messages matter: they are sent at full size every step (no host sync to learn the real count)."""
+    recv = max(4096, 3 * grid_h * 8)
     main = int(n_total / world * headroom) + 4 * grid_h * 10 + 4096
     return main + 2 * recv, recv
 
