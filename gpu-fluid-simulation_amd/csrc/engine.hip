@@ -291,13 +291,13 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     if (s->n == 0) return FS_OK;
 
     if (prof) FS_HIP(hipEventRecord(ev[0], st));
+    // predict + key are fused into the first sort kernel of either mode (no separate launch)
     const bool counting = s->opts.sort_mode == FS_SORT_COUNTING;
-    if (!counting) fsd::launch_predict_key(st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
     if (prof) FS_HIP(hipEventRecord(ev[1], st));
     if (counting) {
         fsd::launch_counting_sort(st, P, s->pos.p, s->vel.p, s->pairs.p, s->cs.p, s->csort.p, s->counter.p);
     } else {
-        fsd::launch_bitonic_sort(st, s->pairs.p, s->n, s->sort_dirty.p);
+        fsd::launch_bitonic_sort(st, s->pairs.p, s->n, s->sort_dirty.p, &P, s->pos.p, s->vel.p, s->counter.p);
     }
     if (prof) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, s->key.p, s->cs.p,

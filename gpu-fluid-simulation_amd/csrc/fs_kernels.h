@@ -8,8 +8,6 @@
 
 namespace fsd {
 
-void launch_predict_key(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, u64* pairs,
-                        uint32_t* gap_counter);
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
                     void* work, uint32_t* counter, uint32_t work_cap, bool cs_ready = false);
@@ -52,7 +50,9 @@ size_t slab_message_bytes(uint32_t R);
 // Bitonic network of sort.wgsl:27-51 / simulation.rs:323-347 on (key<<32 | index) pairs.
 // Returns the number of kernel launches issued.
 // `dirty`: one u32 per 4096-element tile (sort_tile_count(n) entries), scratch owned by the caller.
-int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty);
+// keygen != nullptr: the init pass computes the pairs from pos/vel itself (predict + key fused in).
+int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty, const StepParams* keygen = nullptr,
+                        const float2* pos = nullptr, const float2* vel = nullptr, uint32_t* gap_counter = nullptr);
 uint32_t sort_tile_count(uint32_t n);
 
 // FS_SORT_COUNTING (kernels_csort.hip): fills `pairs` (stable order) and the dense table `cs`.

@@ -12,6 +12,7 @@
 // Elements at index >= n do not exist in the reference (`if index_high >=
 // num_values return`, sort.wgsl:39-41); pairs touching them are skipped.
 #include <stdlib.h>
+#include <string.h>
 
 #include "fs_device.h"
 #include "fs_kernels.h"
@@ -145,9 +146,15 @@ __device__ __forceinline__ void lt_store_l3(u64* __restrict__ pairs, const u64 (
 // A clean tile is still sorted (it was left sorted by the previous stage's tail / the init
 // pass), so every compare of its tail is lower-index <= higher-index: a no-op.  Skipping it
 // is therefore exact, not an approximation.
-template <bool INIT>
+// KEYGEN (2D engine): the init pass also IS predict_next_position + create_spatial_lookup
+// (compute.wgsl:8-42): it reads pos/vel and builds the (key, index) pairs on the fly instead of
+// reading them — one launch and one write+read of the pair array less per step.
+template <bool INIT, bool KEYGEN>
 __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict__ pairs, uint32_t n,
-                                                                uint32_t num_stages, uint32_t* __restrict__ dirty) {
+                                                                uint32_t num_stages, uint32_t* __restrict__ dirty,
+                                                                StepParams P, const float2* __restrict__ pos,
+                                                                const float2* __restrict__ vel,
+                                                                uint32_t* __restrict__ gap_counter) {
     __shared__ u64 s[LT_LDS_ELEMS];
     const uint32_t base = blockIdx.x * SORT_T;
     const uint32_t t = threadIdx.x;
@@ -156,11 +163,21 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
     }
     u64 x[LT_E];
     if (INIT) {
+        if (KEYGEN && blockIdx.x == 0 && t == 0) *gap_counter = 0;      // consumed by k_reorder later in the stream
         // coalesced load, straight into LDS, then the L3 view
 #pragma unroll
         for (int r = 0; r < LT_E; ++r) {
             const uint32_t j = ((uint32_t)r << 8) | t;
-            s[lt_pad(j)] = (base + j < n) ? pairs[base + j] : ~0ull;
+            u64 v = ~0ull;
+            if (base + j < n) {
+                if (KEYGEN) {
+                    const uint32_t i = base + j;
+                    v = ((u64)cell_of_point(P, predict_pos(P, pos[i], vel[i])) << 32) | (u64)i;
+                } else {
+                    v = pairs[base + j];
+                }
+            }
+            s[lt_pad(j)] = v;
         }
         __syncthreads();
         lt_read<0, 3, false>(s, x, t);
@@ -316,14 +333,22 @@ static int sort_skip_stage() {
     return m;   // first stage whose strided passes try the no-op certificate (<0: never)
 }
 
-int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty) {
+int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty, const StepParams* keygen,
+                        const float2* pos, const float2* vel, uint32_t* gap_counter) {
     if (n <= 1) return 0;
     uint32_t p2 = 1, S = 0;
     while (p2 < n) { p2 <<= 1; ++S; }
     const uint32_t tiles = (n + SORT_T - 1) / SORT_T;
     int launches = 0;
     const uint32_t init_stages = S < SORT_LOG_T ? S : SORT_LOG_T;
-    hipLaunchKernelGGL(k_bitonic_local<true>, dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, init_stages, dirty);
+    StepParams P0;
+    memset(&P0, 0, sizeof P0);
+    if (keygen)
+        hipLaunchKernelGGL((k_bitonic_local<true, true>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, init_stages,
+                           dirty, *keygen, pos, vel, gap_counter);
+    else
+        hipLaunchKernelGGL((k_bitonic_local<true, false>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n,
+                           init_stages, dirty, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
     ++launches;                                         // leaves every tile sorted and its flag cleared
     const int skip_from = sort_skip_stage();
     const int mmax = sort_mmax();
@@ -347,7 +372,8 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty)
             a -= (uint32_t)m;
             ++launches;
         }
-        hipLaunchKernelGGL(k_bitonic_local<false>, dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, 0u, dirty);
+        hipLaunchKernelGGL((k_bitonic_local<false, false>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, 0u, dirty,
+                           P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
         ++launches;
     }
     return launches;

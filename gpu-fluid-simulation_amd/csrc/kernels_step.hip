@@ -2,7 +2,8 @@
 //
 // Device state is SoA (float2 pos / vel / pred, f32 density): coalesced 8-byte
 // per-lane streams instead of the reference's 32-byte AoS records.  Pass map:
-//   k_predict_key   = predict_next_position + create_spatial_lookup (compute.wgsl:8-42)
+//   (predict_next_position + create_spatial_lookup, compute.wgsl:8-42, are fused into the first
+//    kernel of the sort: kernels_sort.hip k_bitonic_local<INIT, KEYGEN> / kernels_csort.hip k_cs_hist)
 //   k_reorder       = payload gather after the (key,index) sort + compute_start_indices
 //                     (compute.wgsl:45-56) + dense cell-start table
 //   k_density       = calculate_density (compute.wgsl:59-74, funcs.wgsl:157-203)
@@ -15,18 +16,6 @@
 namespace fsd {
 
 #define FS_BLOCK 256
-
-// ---------------------------------------------------------------- predict + key
-__global__ __launch_bounds__(FS_BLOCK) void k_predict_key(StepParams P, const float2* __restrict__ pos,
-                                                          const float2* __restrict__ vel, u64* __restrict__ pairs,
-                                                          uint32_t* __restrict__ gap_counter) {
-    const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
-    if (i == 0) *gap_counter = 0;   // consumed by k_reorder / k_fill_gaps later in the stream
-    if (i >= P.n) return;
-    const float2 pr = predict_pos(P, pos[i], vel[i]);
-    const uint32_t key = cell_of_point(P, pr);
-    pairs[i] = ((u64)key << 32) | (u64)i;
-}
 
 // --------------------------------------------------- dense cell-start table fill
 // cs[c] = index of the first sorted particle whose key is >= c (c in [0, ncell]).
@@ -542,11 +531,6 @@ void launch_render_density(hipStream_t st, const StepParams& P, float2 wmin, flo
 
 // ------------------------------------------------------------------ launchers
 static inline uint32_t nblk(uint32_t n) { return (n + FS_BLOCK - 1) / FS_BLOCK; }
-
-void launch_predict_key(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, u64* pairs,
-                        uint32_t* gap_counter) {
-    hipLaunchKernelGGL(k_predict_key, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pos, vel, pairs, gap_counter);
-}
 
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
