@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -117,6 +118,8 @@ struct fs_sim {
     DevArray<uint32_t> counter;
     uint32_t work_cap = 0;
     DevArray<fs_particle> aos;      // lazily allocated 32-byte view
+
+    fsd::ConstDiv div_2h3{}, div_h2{};   // exact constant divisions of the force pass, proven at create
 
     // slab (multi-GPU) mode
     bool slab = false;
@@ -233,6 +236,8 @@ fsd::StepParams make_params(const fs_sim& s) {
     P.tex_len = (uint32_t)s.tex.n;
     P.ref_quirks = s.opts.ref_quirks;
     P.fast_math = s.opts.math_mode == FS_MATH_WGSL_ULP ? 1 : 0;
+    P.div_2h3 = s.div_2h3;
+    P.div_h2 = s.div_h2;
     P.col_origin = 0;
     P.own_lo = 0; P.own_hi = s.grid_w;
     P.grid_w_global = s.grid_w;
@@ -248,6 +253,28 @@ fsd::StepParams make_params(const fs_sim& s) {
         P.ref_quirks = 0;   // the global stale-start quirk cannot exist per rank (§8e)
     }
     return P;
+}
+
+// Prove (exhaustively, on the device) that x / c == div_const_fast(x, c, RN(1/c)) for every f32 x.
+fs_status prove_constdiv(hipStream_t st, uint32_t* scratch_word, float c, fsd::ConstDiv* out) {
+    out->c = c;
+    out->y = 1.0f / c;
+    out->ok = 0;
+    if (!(c > 4.0f * FS_CONSTDIV_MIN) || !std::isfinite(c) || !std::isfinite(out->y) || getenv("FS_NO_CONSTDIV")) return FS_OK;
+    uint32_t bad = 1;
+    FS_HIP(hipMemsetAsync(scratch_word, 0, sizeof(uint32_t), st));
+    fsd::launch_verify_constdiv(st, c, out->y, FS_CONSTDIV_MIN, c, scratch_word);   // the kernel's numerators: 2^-60 <= |x| <= c
+    FS_HIP(hipMemcpyAsync(&bad, scratch_word, sizeof bad, hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+    out->ok = bad == 0 ? 1 : 0;
+    return FS_OK;
+}
+
+fs_status prove_force_constants(fs_sim* s) {
+    const float h = s->settings.smoothing_radius;
+    fs_status r = prove_constdiv(s->stream, s->counter.p + 1, 2.0f * h * h * h, &s->div_2h3);   // funcs.wgsl:119
+    if (r != FS_OK) return r;
+    return prove_constdiv(s->stream, s->counter.p + 1, h * h, &s->div_h2);
 }
 
 fs_status ensure_events(fs_sim* s) {
@@ -404,6 +431,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
         FS_TRY(hipStreamSynchronize(s->stream));
     }
 #undef FS_TRY
+    { fs_status r = prove_force_constants(s); if (r != FS_OK) { s->release(); delete s; return r; } }
     fs_tick_settings t0;
     std::memset(&t0, 0, sizeof t0);
     host_uniform(*settings, t0, 0, &s->uniform);
@@ -630,6 +658,26 @@ fs_status fs_timed_steps(fs_sim* s, const fs_tick_settings* t, uint32_t steps, d
     return FS_OK;
 }
 
+/* Exhaustive proof used by the force pass: number of f32 x with lo <= |x| <= hi for which the 3-op
+ * constant division (x*y, fma, fma with the given reciprocal y) differs from the IEEE x / c.  Blocking. */
+fs_status fs_selftest_constdiv(int device, float c, float y, float lo, float hi, uint32_t* mismatches) {
+    if (!mismatches || !(lo > 0.0f) || !(hi >= lo) || !std::isfinite(hi)) return fail(FS_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(FS_ERR_DEVICE, "no HIP device");
+    FS_HIP(hipSetDevice(device));
+    uint32_t* dm = nullptr;
+    FS_HIP(hipMalloc((void**)&dm, sizeof(uint32_t)));
+    FS_HIP(hipMemset(dm, 0, sizeof(uint32_t)));
+    fsd::launch_verify_constdiv(nullptr, c, y, lo, hi, dm);
+    hipError_t e = hipMemcpy(mismatches, dm, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(dm);
+    if (e != hipSuccess) return fail(FS_ERR_DEVICE, hipGetErrorString(e));
+    return FS_OK;
+}
+
+/* Did the create-time proofs succeed for this handle's constants (2h^3, h^2)?  Bits 0 / 1. */
+int fs_constdiv_status(const fs_sim* s) { return s ? (s->div_2h3.ok ? 1 : 0) | (s->div_h2.ok ? 2 : 0) : 0; }
+
 /* ------------------------------------------------------------ slab mode */
 fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_config* cfg, fs_sim** out) {
     if (!settings || !cfg || !out) return fail(FS_ERR_INVALID, "null argument");
@@ -708,6 +756,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(hipMemsetAsync(s->key.p, 0xFF, cap * sizeof(uint32_t), s->stream));
     FS_TRY(hipStreamSynchronize(s->stream));
 #undef FS_TRY
+    { fs_status r = prove_force_constants(s); if (r != FS_OK) { s->release(); delete s; return r; } }
     fs_tick_settings t0;
     std::memset(&t0, 0, sizeof t0);
     host_uniform(*settings, t0, 0, &s->uniform);

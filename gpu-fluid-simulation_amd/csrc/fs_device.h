@@ -12,6 +12,8 @@ namespace fsd {
 
 typedef unsigned long long u64;
 
+struct ConstDiv { float c, y; int32_t ok; };   // exact division by a constant, see div_const() below
+
 // Per-tick parameters, passed by value (replaces the 120-byte uniform buffer,
 // src/uniform.rs:93-95; contents follow src/simulation.rs:470-497).
 struct StepParams {
@@ -35,6 +37,7 @@ struct StepParams {
     uint32_t tex_w_u, tex_len;
     int32_t ref_quirks;
     int32_t fast_math;         // FS_MATH_WGSL_ULP: native rcp/sqrt in the force pass (not bit-exact)
+    ConstDiv div_2h3, div_h2;  // the two constant denominators of funcs.wgsl:119 (2h^3, h^2)
     // --- slab (multi-GPU) mode: the local grid is a window of global cell columns -------------
     int32_t col_origin;        // global column of local column 0 (0 on a single GPU)
     uint32_t own_lo, own_hi;   // owned window [own_lo, own_hi) in GLOBAL columns
@@ -95,6 +98,21 @@ __device__ __forceinline__ float rand_f32(uint32_t* st) {
     x ^= x << 13; x ^= x >> 17; x ^= x << 5;
     *st = x;
     return __fdiv_rn((float)x, 4294967296.0f);
+}
+
+// ---- exact division by a loop-invariant constant ---------------------------------------------
+// x / c  ==  fma(r, y, q0)  with  y = RN(1/c), q0 = RN(x*y), r = fma(-q0, c, x)   (Markstein-style
+// correction; 3 VALU ops instead of the ~11-op / ~36-cycle IEEE sequence).  It is correctly
+// rounded for *most* (c, x); whether it is for EVERY f32 x with the simulation's actual constant
+// is decided by exhaustive enumeration on the GPU when the simulation is created
+// (k_verify_constdiv: all 2^32 bit patterns).  Only constants that pass use this path.
+__device__ __forceinline__ float div_const_fast(float x, float c, float y) {
+    const float q0 = x * y;
+    const float r = __builtin_fmaf(-q0, c, x);
+    return __builtin_fmaf(r, y, q0);
+}
+__device__ __forceinline__ float div_const(const ConstDiv& K, float x) {
+    return K.ok ? div_const_fast(x, K.c, K.y) : __fdiv_rn(x, K.c);     // K.ok is uniform (kernel argument)
 }
 
 // ---- block neighbour tiles (shared by the 2D and 3D density / force kernels) ------------------

@@ -26,6 +26,9 @@ void launch_render_density(hipStream_t st, const StepParams& P, float2 wmin, flo
 // Obstacle push-out field (kernels_field.hip); h <= 1024, w < 65536.
 void launch_gradient_field(hipStream_t st, const unsigned char* image, uint32_t w, uint32_t h, float* dist,
                            uint32_t* nearest, float2* field);
+// Exhaustive proof of fs_device.h div_const_fast over lo <= |x| <= hi (both signs).
+#define FS_CONSTDIV_MIN 8.67361737988403547e-19f   /* 2^-60 */
+void launch_verify_constdiv(hipStream_t st, float c, float y, float lo, float hi, uint32_t* mismatches);
 size_t gap_entry_size();
 void launch_fill_gaps(hipStream_t st, uint32_t* cs, const void* work, const uint32_t* counter, uint32_t work_cap);
 

@@ -8,6 +8,8 @@
 //                     (compute.wgsl:45-56) + dense cell-start table
 //   k_density       = calculate_density (compute.wgsl:59-74, funcs.wgsl:157-203)
 //   k_force         = move_particle + both force sweeps fused (compute.wgsl:79-299)
+#include <string.h>
+
 #include <type_traits>
 
 #include "fs_device.h"
@@ -239,8 +241,23 @@ __device__ __forceinline__ ForceTerms force_terms(const StepParams& P, const flo
         if (dst == 0.0f) {
             kv = P.visc_k;
         } else {
-            kv = P.visc_k * ((fs_div<FAST>(-(dst * dst * dst), 2.0f * h * h * h)) + (fs_div<FAST>(dst * dst, h * h)) +
-                             (fs_div<FAST>(h, 2.0f * dst)) - 1.0f);
+            // the two constant denominators go through div_const (bit-identical to `/`, proven per
+            // constant at create time); 2.0f*h*h*h and h*h are exactly P.div_2h3.c / P.div_h2.c
+            // (proven for FS_CONSTDIV_MIN <= |x| <= c; dst >= 2^-20 puts dst^2 and dst^3 inside, and
+            //  dst <= h keeps them <= h^2 and h^3 = c/2)
+            const bool tiny = dst < 9.5367431640625e-07f;                                   // 2^-20: rare, true division
+            float a, b;
+            if (FAST) {
+                a = fs_div<true>(-(dst * dst * dst), 2.0f * h * h * h);
+                b = fs_div<true>(dst * dst, h * h);
+            } else if (tiny) {
+                a = __fdiv_rn(-(dst * dst * dst), P.div_2h3.c);
+                b = __fdiv_rn(dst * dst, P.div_h2.c);
+            } else {
+                a = div_const(P.div_2h3, -(dst * dst * dst));
+                b = div_const(P.div_h2, dst * dst);
+            }
+            kv = P.visc_k * (a + b + (fs_div<FAST>(h, 2.0f * dst)) - 1.0f);
         }
     }
     T.vx = fs_div<FAST>(nv.x - mv.x, nrho) * kv;                           // compute.wgsl:288
@@ -463,6 +480,29 @@ __global__ __launch_bounds__(FS_BLOCK) void k_import_aos(uint32_t n, const AosPa
     if (i >= n) return;
     const AosParticle a = in[i];
     pos[i] = a.position; pred[i] = a.predicted; vel[i] = a.velocity; rho[i] = a.density; key[i] = a.grid;
+}
+
+// ------------------------------------------------------- proof kernel for div_const
+// Enumerates EVERY f32 x with lo <= |x| <= hi (both signs; lo, hi > 0 given as bit patterns) and
+// counts those for which div_const_fast(x, c, y) differs bitwise from the correctly rounded x / c.
+__global__ __launch_bounds__(FS_BLOCK) void k_verify_constdiv(float c, float y, uint32_t lo_bits, uint32_t hi_bits,
+                                                              uint32_t* __restrict__ mismatches) {
+    const uint32_t tid = blockIdx.x * FS_BLOCK + threadIdx.x;
+    const uint32_t total_threads = gridDim.x * FS_BLOCK;
+    uint32_t bad = 0;
+    for (uint64_t b = (uint64_t)lo_bits + tid; b <= (uint64_t)hi_bits; b += total_threads) {
+        const float x = __uint_as_float((uint32_t)b);                 // positive floats are ordered like their bits
+        bad += __float_as_uint(div_const_fast(x, c, y)) != __float_as_uint(__fdiv_rn(x, c)) ? 1u : 0u;
+        bad += __float_as_uint(div_const_fast(-x, c, y)) != __float_as_uint(__fdiv_rn(-x, c)) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+void launch_verify_constdiv(hipStream_t st, float c, float y, float lo, float hi, uint32_t* mismatches) {
+    uint32_t lb, hb;
+    memcpy(&lb, &lo, 4);
+    memcpy(&hb, &hi, 4);
+    hipLaunchKernelGGL(k_verify_constdiv, dim3(256 * 32), dim3(FS_BLOCK), 0, st, c, y, lb, hb, mismatches);
 }
 
 // ------------------------------------------------------- density-splat image (fluid_shader.wgsl:27-102)

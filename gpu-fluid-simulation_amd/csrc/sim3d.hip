@@ -29,6 +29,7 @@ struct Params3 {
     float mass, poly6, pressure_k, rest_density, damping, visc_coeff, spiky, visc_k;
     float gx, gy, gz;
     uint32_t frame;
+    ConstDiv div_2h3, div_h2;    // exact constant divisions, proven at create (fs_device.h div_const)
 };
 
 #define B3 256
@@ -183,10 +184,21 @@ __device__ __forceinline__ Terms3 terms3(const Params3& P, float4 me, float4 mv,
     const float kern = (dst <= h) ? (-(h - dst)) * P.spiky : 0.0f;
     const float shared = (pressure + npress) * 0.5f;
     float kv = 0.0f;
-    if (dst <= h)
-        kv = (dst == 0.0f) ? P.visc_k
-                           : P.visc_k * ((__fdiv_rn(-(dst * dst * dst), 2.0f * h * h * h)) + (__fdiv_rn(dst * dst, h * h)) +
-                                         (__fdiv_rn(h, 2.0f * dst)) - 1.0f);
+    if (dst <= h) {
+        if (dst == 0.0f) {
+            kv = P.visc_k;
+        } else {
+            float a, b;
+            if (dst < 9.5367431640625e-07f) {            // 2^-20: outside the proven range, true division
+                a = __fdiv_rn(-(dst * dst * dst), P.div_2h3.c);
+                b = __fdiv_rn(dst * dst, P.div_h2.c);
+            } else {
+                a = div_const(P.div_2h3, -(dst * dst * dst));
+                b = div_const(P.div_h2, dst * dst);
+            }
+            kv = P.visc_k * (a + b + (__fdiv_rn(h, 2.0f * dst)) - 1.0f);
+        }
+    }
     Terms3 T;
     T.px = __fdiv_rn(dx * kern * shared, nrho);
     T.py = __fdiv_rn(dy * kern * shared, nrho);
@@ -348,6 +360,7 @@ struct fs_sim3 {
     uint32_t pending = 0;
     double ms[FS_PASS_COUNT] = {};
     uint64_t steps = 0;
+    fsd::ConstDiv div_2h3{}, div_h2{};
     void release() {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); key.release(); cs.release();
         counter.release(); dirty.release(); pairs.release(); work.release(); aos.release();
@@ -393,6 +406,8 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     P.visc_coeff = t->viscosity_coefficient;
     P.gx = t->gravity.x; P.gy = t->gravity.y; P.gz = t->gravity.z;
     P.frame = s->tick;
+    P.div_2h3 = s->div_2h3;
+    P.div_h2 = s->div_h2;
     hipStream_t st = s->stream;
     hipEvent_t* ev = nullptr;
     if (s->profile) {
@@ -467,6 +482,20 @@ fs_status fs3_create(const fs3_settings* st, int device, fs_vec3 off, fs_sim3** 
         hipLaunchKernelGGL(fsd::k3_import, dim3((s->n + B3 - 1) / B3), dim3(B3), 0, s->stream, s->n, s->aos.p, s->pos.p,
                            s->pred.p, s->vel.p, s->key.p);
         T3(hipStreamSynchronize(s->stream));
+    }
+    for (int k = 0; k < 2; ++k) {   // prove the two constant divisions for this h (see engine.hip prove_constdiv)
+        fsd::ConstDiv& K = k == 0 ? s->div_2h3 : s->div_h2;
+        const float hh = st->smoothing_radius;
+        K.c = k == 0 ? 2.0f * hh * hh * hh : hh * hh;
+        K.y = 1.0f / K.c;
+        K.ok = 0;
+        if (!(K.c > 4.0f * FS_CONSTDIV_MIN) || !std::isfinite(K.c) || !std::isfinite(K.y)) continue;
+        uint32_t bad = 1;
+        T3(hipMemsetAsync(s->counter.p + 1, 0, 4, s->stream));
+        fsd::launch_verify_constdiv(s->stream, K.c, K.y, FS_CONSTDIV_MIN, K.c, s->counter.p + 1);
+        T3(hipMemcpyAsync(&bad, s->counter.p + 1, 4, hipMemcpyDeviceToHost, s->stream));
+        T3(hipStreamSynchronize(s->stream));
+        K.ok = bad == 0 ? 1 : 0;
     }
 #undef T3
     *out = s;

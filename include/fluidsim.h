@@ -328,6 +328,16 @@ size_t fs_buffer_len(const fs_buffer* buf);      /* SSBO::len (src/buffer.rs:170
 void* fs_buffer_device_ptr(const fs_buffer* buf); /* bind_group() equivalent (src/buffer.rs:162-164) */
 void fs_buffer_destroy(fs_buffer* buf);
 
+/* ------------------------------------------------------------- self-tests */
+/* The force pass divides by two loop-invariant constants (2h^3, h^2; funcs.wgsl:119).  At create
+ * time the engine PROVES, by enumerating on the GPU every f32 numerator the kernel can feed it
+ * (2^-60 <= |x| <= c, both signs; smaller ones take the true division), that a 3-instruction
+ * form is bit-identical to the IEEE division for the handle's constants; only then is it used.
+ * fs_selftest_constdiv exposes that enumeration (mismatch count for constant c, reciprocal y and
+ * range [lo, hi]); fs_constdiv_status returns bit 0 / bit 1 = proof succeeded for 2h^3 / h^2. */
+fs_status fs_selftest_constdiv(int device, float c, float y, float lo, float hi, uint32_t* mismatches);
+int fs_constdiv_status(const fs_sim* sim);
+
 /* ----------------------------------------------------------------- errors */
 const char* fs_last_error(void);  /* thread-local, never NULL */
 int fs_abi_version(void);
