@@ -115,6 +115,19 @@ __device__ __forceinline__ float div_const(const ConstDiv& K, float x) {
     return K.ok ? div_const_fast(x, K.c, K.y) : __fdiv_rn(x, K.c);     // K.ok is uniform (kernel argument)
 }
 
+// ---- XCD-aware block index ---------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one; MI355X guide, "Workgroup
+// dispatch").  A strip of particles and the strips one grid row above/below it (~64 blocks away)
+// read the same neighbour rows, so each XCD is given ONE contiguous eighth of the strips: its
+// private 4 MB L2 then holds the few rows it is working on instead of every XCD streaming all of
+// them.  Launch ceil(nblocks/8)*8 blocks; returns false for the padding blocks.  Speed only.
+__device__ __forceinline__ bool xcd_block(uint32_t nblocks, uint32_t* logical) {
+    const uint32_t per = (nblocks + 7u) >> 3;
+    const uint32_t lb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    *logical = lb;
+    return lb < nblocks;
+}
+
 // ---- block neighbour tiles (shared by the 2D and 3D density / force kernels) ------------------
 // A 256-thread workgroup owns 256 consecutive sorted particles (a strip of cells in one grid
 // row), so the candidates of ALL its lanes for one sweep row form one short contiguous index
