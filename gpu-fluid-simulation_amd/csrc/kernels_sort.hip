@@ -1,16 +1,19 @@
 // kernels_sort.hip — the reference's bitonic network (sort.wgsl:27-51, schedule
 // src/simulation.rs:323-347) on 8-byte (key<<32 | source index) pairs.
 //
-// The reference issues S(S+1)/2 full-array dispatches over 32-byte records.  The
-// network is data-oblivious and compares keys only (strict `>`, so equal keys
-// never swap), hence sorting pairs and gathering the payload afterwards yields
-// the bit-identical arrangement.  Here every step whose compare distance fits a
-// workgroup tile runs out of LDS:
-//   * k_bitonic_local<INIT>: stages 0..LOG_T-1 entirely inside one tile;
-//   * k_bitonic_global:      one step with block size > tile (HBM pass);
-//   * k_bitonic_local<TAIL>: the remaining steps of a stage (distance T/2..1).
-// Elements at index >= n do not exist in the reference (`if index_high >=
-// num_values return`, sort.wgsl:39-41); pairs touching them are skipped.
+// The reference issues S(S+1)/2 full-array dispatches over 32-byte records.  The network is
+// data-oblivious and compares keys only (strict `>`, so equal keys never swap), hence sorting
+// pairs and gathering the payload afterwards yields the bit-identical arrangement.  Structure:
+//   * k_bitonic_local<INIT,KEYGEN>: predict + key (compute.wgsl:8-42) fused into the tile load, then
+//                                   stages 0..11 entirely inside a 4096-pair tile (registers + LDS);
+//   * k_bitonic_strided<M,FLIP>:    up to M steps of a later stage whose partners lie in different
+//                                   tiles, in registers (one HBM/MALL pass per M steps);
+//   * k_bitonic_local<TAIL>:        the last 12 steps of a stage, inside a tile.
+// Provable no-ops are skipped (per-tile dirty flags, ordered-chunk certificates): see the
+// comments at k_bitonic_local and k_bitonic_strided.
+// Elements at index >= n do not exist in the reference (`if index_high >= num_values return`,
+// sort.wgsl:39-41); here they hold a sentinel pair that can never swap (its key is the u32
+// maximum and the compare is strict), which is equivalent.
 #include <stdlib.h>
 #include <string.h>
 

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
     const float2 v = vel_in[src];
     pos_s[i] = p;
     vel_s[i] = v;
-    pred_s[i] = predict_pos(P, p, v);   // same expression as k_predict_key -> same bits
+    pred_s[i] = predict_pos(P, p, v);   // same expression as the key generation in the sort -> same bits
     key_s[i] = key;
 
     const uint32_t kc = key < P.ncell ? key : P.ncell;   // clamp for table writes only
