@@ -36,25 +36,38 @@ ALG_BYTES_3D = {"predict_key": 40, "sort": 12, "reorder": 72 + 4, "density": 20,
 ALG_TOTAL_3D = 216
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The CPU oracle (scalar C++ port of the reference step) timed on this host, 1 thread,
-    on a bounded sample of the same scene: 1M-particle dam break, as many steps as fit."""
+def cpu_baseline(seconds_budget=15.0):
+    """The CPU oracle (C++ port of the reference step) timed on this host on a bounded sample of the same
+    scene (1M-particle dam break, as many steps as fit): the scalar port (1 thread) is THE cpu_baseline;
+    the same port with OpenMP over particles on all cores is reported beside it."""
     import gpu_fluid_simulation_amd as g
     from oracle import oracle as O
     n = 1 << 20
     st, off, tick = g.dam_break_2d(n)
-    sim = O.OracleSim(st, off)
-    sim.step(tick)                      # warm-up (page faults, first sort of the lattice)
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        sim.step(tick)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or steps >= 64:
-            break
-    return {"value": round(n * steps / el / 1e6, 4), "unit": "M particle-steps/s", "cores": 1, "kind": "port",
-            "sample": f"dam_break_2d 1M particles, {steps} steps after 1 warm-up, oracle/sph_oracle.cpp scalar, "
-                      f"{el:.1f} s on {os.cpu_count()} host cores (1 used)"}
+
+    def run(threads, budget):
+        O.set_threads(threads)
+        sim = O.OracleSim(st, off)
+        sim.step(tick)                  # warm-up (page faults, first sort of the lattice)
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            sim.step(tick)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > budget or steps >= 64:
+                break
+        sim.close()
+        O.set_threads(1)
+        return n * steps / el / 1e6, steps, el
+
+    v1, s1, e1 = run(1, seconds_budget)
+    cores = max(1, min(O.max_threads(), len(os.sched_getaffinity(0))))
+    vN, sN, eN = run(cores, seconds_budget / 3)
+    return {"value": round(v1, 4), "unit": "M particle-steps/s", "cores": 1, "kind": "port",
+            "sample": f"dam_break_2d 1M particles, {s1} steps after 1 warm-up, oracle/sph_oracle.cpp scalar, "
+                      f"{e1:.1f} s on {os.cpu_count()} host cores (1 used)",
+            "all_cores": {"value": round(vN, 3), "cores": cores,
+                          "sample": f"same port, OpenMP over particles, {sN} steps in {eN:.1f} s"}}
 
 
 def main():

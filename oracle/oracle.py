@@ -41,6 +41,9 @@ def lib():
         L.orc_density.argtypes = [P, C.c_int]
         L.orc_step.argtypes = [P, P]
         L.orc_step_stable.argtypes = [P, P]
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_max_threads.restype = C.c_int
+        L.orc_set_threads(1)                      # the oracle is a scalar port unless a caller asks for more
         L.orc_gradient_field.argtypes = [P, C.c_uint32, C.c_uint32, P]
         L.orc_render.argtypes = [P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, P]
         L.orc_tick.restype = C.c_uint32
@@ -216,6 +219,15 @@ class OracleSim:
         out = (C.c_char * 120)()
         self.L.orc_uniform(self.h, C.addressof(out))
         return bytes(out)
+
+
+def set_threads(n):
+    """OpenMP threads for the oracle's per-particle loops (results are identical for any count)."""
+    lib().orc_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
 
 
 def gradient_field(image):

@@ -16,6 +16,8 @@
  * the reference tree).  All arithmetic is IEEE f32, evaluated in the written
  * association; build with -ffp-contract=off (see oracle/Makefile).
  */
+#include <omp.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -141,6 +143,7 @@ inline uint32_t grid_pos_to_id(const fs_uniform& u, uint32_t x, uint32_t y) { re
 void predict(OrcSim& s) {
     const fs_uniform& u = s.u;
     const float bsx = u.bounds.x * 0.5f, bsy = u.bounds.y * 0.5f;
+#pragma omp parallel for schedule(static)
     for (uint32_t i = 0; i < u.particle_count; ++i) {
         fs_particle& q = s.p[i];
         q.predicted_position.x = q.position.x + q.velocity.x * u.delta;   // :16
@@ -152,6 +155,7 @@ void predict(OrcSim& s) {
 
 // compute.wgsl:33-42 + funcs.wgsl:206-218
 void spatial_lookup(OrcSim& s) {
+#pragma omp parallel for schedule(static)
     for (uint32_t i = 0; i < s.u.particle_count; ++i) {
         uint32_t cx, cy;
         xy_of_point(s.u, s.p[i].predicted_position, &cx, &cy);
@@ -192,6 +196,7 @@ void bitonic_network(T* v, uint32_t n, KeyOf key) {
     for (uint32_t stage = 0; stage < stages; ++stage) {
         for (uint32_t step = 0; step <= stage; ++step) {
             const uint32_t gw = 1u << (stage - step), gh = 2 * gw - 1;
+#pragma omp parallel for schedule(static) if (threads > 65536)      // pairs of one dispatch are disjoint
             for (uint32_t i = 0; i < threads; ++i) {                       // sort.wgsl:29-50
                 const uint32_t hh = i & (gw - 1);
                 const uint32_t lo = hh + (gh + 1) * (i / gw);
@@ -247,6 +252,7 @@ inline void walk_cell(const OrcSim& s, const std::vector<fs_particle>& arr, uint
 // sweep as written; 1 is the bit-identical 3x3 sweep.
 void density(OrcSim& s, int reach) {
     const fs_uniform& u = s.u;
+#pragma omp parallel for schedule(dynamic, 1024)
     for (uint32_t pi = 0; pi < u.particle_count; ++pi) {
         const fs_vec2 point = s.p[pi].predicted_position;
         uint32_t cxu, cyu;
@@ -375,6 +381,7 @@ void move_particles(OrcSim& s) {
     s.snap = s.p;
     const std::vector<fs_particle>& src = s.snap;
     const uint32_t tex_w = f32_to_u32_sat(u.texture_size.x);
+#pragma omp parallel for schedule(dynamic, 1024)
     for (uint32_t id = 0; id < u.particle_count; ++id) {
         fs_particle q = src[id];
         const fs_vec2 fp = pressure_force(s, src, id);
@@ -443,6 +450,11 @@ void move_particles(OrcSim& s) {
 extern "C" {
 
 typedef struct orc_sim orc_sim;
+
+/* Threads used by the passes above (default 1 = the scalar port).  Results do not depend on it:
+ * every pass is independent per particle / per disjoint pair. */
+void orc_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
+int orc_max_threads(void) { return omp_get_num_procs(); }
 
 orc_sim* orc_create(const fs_settings* st, float off_x, float off_y, int ref_quirks) {
     if (!st || st->particle_count <= 1) return nullptr;   // simulation.rs:323-324 would panic
