@@ -36,6 +36,19 @@ ALG_BYTES_3D = {"predict_key": 40, "sort": 12, "reorder": 72 + 4, "density": 20,
 ALG_TOTAL_3D = 216
 
 
+def usable_cores():
+    """CPU share of this process: cgroup quota if there is one (a GPU box gives each job a slice of a
+    256-thread host), else the affinity mask; capped at 16 as the box's per-GPU share."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(seconds_budget=15.0):
     """The CPU oracle (C++ port of the reference step) timed on this host on a bounded sample of the same
     scene (1M-particle dam break, as many steps as fit): the scalar port (1 thread) is THE cpu_baseline;
@@ -61,7 +74,7 @@ def cpu_baseline(seconds_budget=15.0):
         return n * steps / el / 1e6, steps, el
 
     v1, s1, e1 = run(1, seconds_budget)
-    cores = max(1, min(O.max_threads(), len(os.sched_getaffinity(0))))
+    cores = min(usable_cores(), O.max_threads())
     vN, sN, eN = run(cores, seconds_budget / 3)
     return {"value": round(v1, 4), "unit": "M particle-steps/s", "cores": 1, "kind": "port",
             "sample": f"dam_break_2d 1M particles, {s1} steps after 1 warm-up, oracle/sph_oracle.cpp scalar, "
