@@ -325,7 +325,7 @@ static void launch_strided(hipStream_t st, u64* pairs, uint32_t n, uint32_t a, b
 static int sort_mmax() {
     static int m = [] {
         const char* e = getenv("FS_SORT_MMAX");
-        int v = e ? atoi(e) : 5;
+        int v = e ? atoi(e) : 4;   // measured over the bench window @16M: 2: 0.90 ms, 3: 0.74, 4: 0.706, 5: 0.718, 6: 0.79
         return v < 1 ? 1 : (v > 6 ? 6 : v);
     }();
     return m;
