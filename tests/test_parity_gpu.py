@@ -365,3 +365,41 @@ def test_64m_properties(fs):
     assert np.isfinite(p["position"]).all() and np.isfinite(p["velocity"]).all()
     assert np.unique(p["position"].view(np.uint64)).shape[0] == n          # nobody lost or duplicated
     assert np.median(p["density"]) == pytest.approx(101.46, rel=1e-3)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_configurations(fs, orc, case):
+    """Seeded random settings (smoothing radius, spacing, domain aspect, dt, mass, stiffness, rest density,
+    damping, viscosity, gravity sign, texture size, mouse) and particle counts: bit-exact in both sort modes."""
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.integers(2, 6000))
+    h = float(rng.choice([0.05, 0.1, 0.2, 0.33, 0.5, 1.0]))
+    spacing = float(h * rng.uniform(0.3, 0.9))
+    side = np.sqrt(n) * spacing
+    size = (float(side * rng.uniform(1.2, 3.0) + 4 * h), float(side * rng.uniform(1.2, 3.0) + 4 * h))
+    tex = (int(rng.choice([64, 256, 1024])), int(rng.choice([64, 128, 1024])))
+    st = fs.SimulationSettings(n, spacing, h, size, tex)
+    tick = fs.default_tick_settings(
+        delta=float(rng.choice([1 / 240, 1 / 120, 1 / 60])), gravity=(float(rng.uniform(-5, 5)), float(rng.uniform(-10, 10))),
+        mass=float(rng.uniform(0.5, 2.0)), pressure_constant=float(rng.uniform(5, 100)),
+        rest_density=float(rng.choice([0.0, 1.0, 20.0])), damping_factor=float(rng.uniform(0.0, 0.9)),
+        viscosity_coefficient=float(rng.choice([0.0, 5.0, 25.0])), mouse_state=int(rng.choice([0, 0, 1, -1])),
+        mouse_pos=(float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))), mouse_force_radius=float(rng.uniform(0.5, 5)))
+    off = (float(rng.uniform(-0.2, 0.2) * size[0]), float(rng.uniform(-0.2, 0.2) * size[1]))
+    for mode, stable in ((fs.FS_SORT_BITONIC, False), (fs.FS_SORT_COUNTING, True)):
+        sim = fs.FluidSimulation(st, device=0, initial_offset=off, sort_mode=mode)
+        ref = orc.OracleSim(st, off)
+        p = ref.particles()
+        p["position"] += rng.uniform(-0.3, 0.3, size=(n, 2)).astype(np.float32) * np.float32(spacing)
+        p["predicted_position"] = p["position"]
+        p["velocity"] = (rng.standard_normal((n, 2)) * 2.0).astype(np.float32)
+        ref.set_particles(p); sim.upload_particles(p)
+        if case % 3 == 0:
+            field = np.zeros((tex[1], tex[0], 2), dtype=np.float32)
+            field[tex[1] // 3: tex[1] // 2, tex[0] // 4: tex[0] // 2] = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)))
+            sim.upload_force_field(field); ref.texture_view()[:] = field
+        for s in range(4):
+            sim.tick(tick); ref.step(tick, stable_sort=stable)
+            assert_particles_equal(sim.download_particles(), ref.particles(), f"random case {case} mode {mode} step {s}")
+            assert np.array_equal(sim.download_start_indices(), ref.start_indices())
+        sim.close(); ref.close()
