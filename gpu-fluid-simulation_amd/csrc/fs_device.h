@@ -120,12 +120,15 @@ __device__ __forceinline__ float div_const(const ConstDiv& K, float x) {
 // dispatch").  A strip of particles and the strips one grid row above/below it (~64 blocks away)
 // read the same neighbour rows, so each XCD is given ONE contiguous eighth of the strips: its
 // private 4 MB L2 then holds the few rows it is working on instead of every XCD streaming all of
-// them.  Launch ceil(nblocks/8)*8 blocks; returns false for the padding blocks.  Speed only.
+// them.  `nblocks` = blocks that hold live particles (in slab mode the grid covers the whole
+// capacity; mapping over that would park the dead tail on the last XCDs and idle them).  The
+// grid must have at least ceil(nblocks/8)*8 blocks; returns false for blocks with no work.
 __device__ __forceinline__ bool xcd_block(uint32_t nblocks, uint32_t* logical) {
     const uint32_t per = (nblocks + 7u) >> 3;
-    const uint32_t lb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t lb = (blockIdx.x & 7u) * per + slot;
     *logical = lb;
-    return lb < nblocks;
+    return slot < per && lb < nblocks;
 }
 
 // ---- block neighbour tiles (shared by the 2D and 3D density / force kernels) ------------------

@@ -130,15 +130,13 @@ __device__ __forceinline__ float density_term(const StepParams& P, float h2, flo
 __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2* __restrict__ pred,
                                                       const uint32_t* __restrict__ cs,
                                                       const uint32_t* __restrict__ start_ref,
-                                                      const u64* __restrict__ pairs, float* __restrict__ rho_out,
-                                                      uint32_t nblocks) {
+                                                      const u64* __restrict__ pairs, float* __restrict__ rho_out) {
     __shared__ float2 s_pred[3][NB_TILE];
     __shared__ uint32_t s_red[24];
-    uint32_t blk;
-    if (!xcd_block(nblocks, &blk)) return;
-    const uint32_t i = blk * FS_BLOCK + threadIdx.x;
     const uint32_t n = P.n_live ? *P.n_live : P.n;
-    if (blk * FS_BLOCK >= n) return;                        // whole block dead (uniform)
+    uint32_t blk;
+    if (!xcd_block((n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;      // uniform: no live particle in this block
+    const uint32_t i = blk * FS_BLOCK + threadIdx.x;
     const bool live = i < n;
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
     const float2 me = pred[live ? i : n - 1];
@@ -358,17 +356,15 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
                                                     const uint32_t* __restrict__ cs,
                                                     const uint32_t* __restrict__ start_ref,
                                                     const u64* __restrict__ pairs, const float2* __restrict__ tex,
-                                                    float2* __restrict__ pos_out, float2* __restrict__ vel_out,
-                                                    uint32_t nblocks) {
+                                                    float2* __restrict__ pos_out, float2* __restrict__ vel_out) {
     __shared__ unsigned short s_list[FORCE_CAP * FS_BLOCK];
     __shared__ float2 s_pred[3][NBF_TILE];
     __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
-    uint32_t blk;
-    if (!xcd_block(nblocks, &blk)) return;
-    const uint32_t i = blk * FS_BLOCK + tid;
     const uint32_t n = P.n_live ? *P.n_live : P.n;
-    if (blk * FS_BLOCK >= n) return;                 // whole block dead (uniform)
+    uint32_t blk;
+    if (!xcd_block((n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;      // uniform: no live particle in this block
+    const uint32_t i = blk * FS_BLOCK + tid;
     bool live = i < n;
     const uint32_t ii = live ? i : n - 1;            // dead lanes shadow the last particle, store nothing
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
@@ -594,7 +590,7 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
                     const uint32_t* start_ref, const u64* pairs, float* rho) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
-    hipLaunchKernelGGL(k_density, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, rho, nb);
+    hipLaunchKernelGGL(k_density, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, rho);
 }
 
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
@@ -603,10 +599,10 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
     if (P.fast_math)
         hipLaunchKernelGGL(k_force<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho, cs,
-                           start_ref, pairs, tex, pos_out, vel_out, nb);
+                           start_ref, pairs, tex, pos_out, vel_out);
     else
         hipLaunchKernelGGL(k_force<false>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho, cs,
-                           start_ref, pairs, tex, pos_out, vel_out, nb);
+                           start_ref, pairs, tex, pos_out, vel_out);
 }
 
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
