@@ -38,9 +38,11 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_classify(StepParams P, uint32
                                                             const unsigned char* __restrict__ owned,
                                                             u64* __restrict__ pairs, unsigned char* __restrict__ flags,
                                                             uint2* __restrict__ blockcnt,
-                                                            uint32_t* __restrict__ counters) {
+                                                            uint32_t* __restrict__ counters,
+                                                            uint32_t* __restrict__ gap_counter) {
     __shared__ uint32_t s_cnt[2 * (SL_BLOCK / 64)];
     const uint32_t i = blockIdx.x * SL_BLOCK + threadIdx.x;
+    if (i == 0) *gap_counter = 0;          // cell-table worklist of this step (k_slab_reorder / counting sort)
     const uint32_t n_prev = *P.n_live;
     unsigned char f = 0;
     if (i < main_slots) {
@@ -71,34 +73,53 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_classify(StepParams P, uint32
 
 struct SlabHeader { uint32_t count, overflow, pad0, pad1; };
 
-// Exclusive scan of the per-block counts (one workgroup; nblocks is a few thousand).
-__global__ __launch_bounds__(SL_BLOCK) void k_slab_scan(const uint2* __restrict__ blockcnt, uint32_t nblocks,
-                                                        uint2* __restrict__ blockoff, SlabHeader* hdr_left,
-                                                        SlabHeader* hdr_right, uint32_t R,
-                                                        uint32_t* __restrict__ counters) {
-    __shared__ uint2 s_sum[SL_BLOCK];
-    const uint32_t chunk = (nblocks + SL_BLOCK - 1) / SL_BLOCK;
+// Exclusive scan of the per-block counts.  One workgroup of 1024 threads; every thread owns a
+// contiguous chunk and reads it with independent 16-byte loads (two counts each), so the ~10^4-10^5
+// counts of a slab cost a few microseconds instead of a serial walk.
+#define SCAN_THREADS 1024
+__global__ __launch_bounds__(SCAN_THREADS) void k_slab_scan(const uint2* __restrict__ blockcnt, uint32_t nblocks,
+                                                            uint2* __restrict__ blockoff, SlabHeader* hdr_left,
+                                                            SlabHeader* hdr_right, uint32_t R,
+                                                            uint32_t* __restrict__ counters) {
+    __shared__ uint2 s_sum[SCAN_THREADS];
+    __shared__ uint2 s_wave[SCAN_THREADS / 64];
+    uint32_t chunk = (nblocks + SCAN_THREADS - 1) / SCAN_THREADS;
+    chunk = (chunk + 1u) & ~1u;                                   // even, so chunks start 16-byte aligned
     const uint32_t b0 = threadIdx.x * chunk;
+    const uint32_t b1 = b0 + chunk < nblocks ? b0 + chunk : nblocks;
     uint2 acc = make_uint2(0, 0);
-    for (uint32_t b = b0; b < b0 + chunk && b < nblocks; ++b) { acc.x += blockcnt[b].x; acc.y += blockcnt[b].y; }
-    s_sum[threadIdx.x] = acc;
+    uint32_t b = b0;
+    for (; b + 8u <= b1; b += 8u) {                               // 4 independent uint4 loads in flight
+        const uint4 v0 = *reinterpret_cast<const uint4*>(blockcnt + b), v1 = *reinterpret_cast<const uint4*>(blockcnt + b + 2);
+        const uint4 v2 = *reinterpret_cast<const uint4*>(blockcnt + b + 4), v3 = *reinterpret_cast<const uint4*>(blockcnt + b + 6);
+        acc.x += v0.x + v0.z + v1.x + v1.z + v2.x + v2.z + v3.x + v3.z;
+        acc.y += v0.y + v0.w + v1.y + v1.w + v2.y + v2.w + v3.y + v3.w;
+    }
+    for (; b < b1; ++b) { acc.x += blockcnt[b].x; acc.y += blockcnt[b].y; }
+    // exclusive scan of the 1024 chunk sums: wave scan + scan of the 16 wave totals
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint2 inc = acc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t tx = __shfl_up(inc.x, o), ty = __shfl_up(inc.y, o);
+        if ((int)lane >= o) { inc.x += tx; inc.y += ty; }
+    }
+    if (lane == 63u) s_wave[w] = inc;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint2 run = make_uint2(0, 0);
-        for (uint32_t t = 0; t < SL_BLOCK; ++t) {
-            const uint2 v = s_sum[t];
-            s_sum[t] = run;
-            run.x += v.x; run.y += v.y;
-        }
+        for (uint32_t k = 0; k < SCAN_THREADS / 64; ++k) { const uint2 v = s_wave[k]; s_wave[k] = run; run.x += v.x; run.y += v.y; }
         if (hdr_left) { hdr_left->count = run.x < R ? run.x : R; hdr_left->overflow = run.x > R; }
         if (hdr_right) { hdr_right->count = run.y < R ? run.y : R; hdr_right->overflow = run.y > R; }
         if (run.x > R || run.y > R) atomicAdd(&counters[3], 1u);
     }
     __syncthreads();
-    uint2 run = s_sum[threadIdx.x];
-    for (uint32_t b = b0; b < b0 + chunk && b < nblocks; ++b) {
+    uint2 run = make_uint2(s_wave[w].x + inc.x - acc.x, s_wave[w].y + inc.y - acc.y);
+    (void)s_sum;
+    for (b = b0; b < b1; ++b) {
+        const uint2 v = blockcnt[b];
         blockoff[b] = run;
-        run.x += blockcnt[b].x; run.y += blockcnt[b].y;
+        run.x += v.x; run.y += v.y;
     }
 }
 
@@ -272,12 +293,11 @@ void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, 
                       unsigned char* flags, void* blockcnt, void* blockoff, void* msg_left, void* msg_right,
                       uint32_t* counters, uint32_t* gap_counter) {
     const uint32_t blocks = nb(main_slots);
-    (void)hipMemsetAsync(gap_counter, 0, sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_slab_classify, dim3(blocks), dim3(SL_BLOCK), 0, st, P, main_slots, has_left, has_right, pos,
-                       vel, owned, pairs, flags, (uint2*)blockcnt, counters);
+                       vel, owned, pairs, flags, (uint2*)blockcnt, counters, gap_counter);
     SlabHeader* hl = (SlabHeader*)msg_left;
     SlabHeader* hr = (SlabHeader*)msg_right;
-    hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SL_BLOCK), 0, st, (const uint2*)blockcnt, blocks, (uint2*)blockoff,
+    hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SCAN_THREADS), 0, st, (const uint2*)blockcnt, blocks, (uint2*)blockoff,
                        hl, hr, R, counters);
     hipLaunchKernelGGL(k_slab_scatter, dim3(blocks), dim3(SL_BLOCK), 0, st, main_slots, pos, vel, flags,
                        (const uint2*)blockoff, hl ? (float4*)(hl + 1) : nullptr, hr ? (float4*)(hr + 1) : nullptr, R);
