@@ -90,6 +90,16 @@ __device__ __forceinline__ void lt_write(u64* s, const u64 (&x)[LT_E], uint32_t 
     }
 }
 
+// L2 <-> L3 re-distribution only exchanges data between the 16 consecutive threads that share
+// t >> 4 (L2 thread (hi4, lo4) owns idx = hi4<<8 | r<<4 | lo4, which in L3 belongs to thread
+// hi4<<4 | r): always inside one wave.  A wave's LDS instructions execute in program order, so
+// no workgroup barrier is needed there — only a compiler-level fence.  L1 <-> L2/L3 crosses waves.
+__device__ __forceinline__ void lt_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Stage S (0..3) entirely on in-thread bits of L3.
 template <int S>
 __device__ __forceinline__ void lt_stage_regs(u64 (&x)[LT_E]) {
@@ -105,11 +115,11 @@ __device__ __forceinline__ void lt_stage_regs(u64 (&x)[LT_E]) {
 template <int S>
 __device__ __forceinline__ void lt_stage_mid(u64* s, u64 (&x)[LT_E], uint32_t t) {
     lt_write<0, 3, false>(s, x, t);
-    __syncthreads();
+    lt_wave_sync();                       // L3 -> L2 (mirrored reads stay inside the 2^(S+1) block, S <= 7: same 16 threads)
     lt_read<4, S - 4, true>(s, x, t);
     lt_round<S - 4, true>(x);
     lt_write<4, S - 4, true>(s, x, t);
-    __syncthreads();
+    lt_wave_sync();                       // L2 -> L3
     lt_read<0, 3, false>(s, x, t);
     lt_round<3, false>(x);
 }
@@ -126,7 +136,7 @@ __device__ __forceinline__ void lt_stage_high(u64* s, u64 (&x)[LT_E], uint32_t t
     lt_read<4, 3, false>(s, x, t);
     lt_round<3, false>(x);
     lt_write<4, 3, false>(s, x, t);
-    __syncthreads();
+    lt_wave_sync();                       // L2 -> L3
     lt_read<0, 3, false>(s, x, t);
     lt_round<3, false>(x);
 }
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
         lt_read<4, 3, false>(s, x, t);
         lt_round<3, false>(x);
         lt_write<4, 3, false>(s, x, t);
-        __syncthreads();
+        lt_wave_sync();                   // L2 -> L3
         lt_read<0, 3, false>(s, x, t);
         lt_round<3, false>(x);
     }
