@@ -124,19 +124,21 @@ def test_slab_rebalancing_keeps_parity_and_conserves(fs):
     assert_statistics_close(slabs.owned(), single.download_particles(), n)
 
 
-def test_two_rank_bench_rehearsal_gloo(fs):
-    """bench.py --gpus 2 launched as two ranks that share GPU 0 (RCCL refuses two ranks on one
-    device, so the rehearsal uses gloo with host-staged messages; the driver's real run uses nccl)."""
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_multi_rank_bench_rehearsal_gloo(fs, ranks):
+    """bench.py --gpus N launched as N ranks that share GPU 0 (RCCL refuses several ranks on one
+    device, so the rehearsal uses gloo with host-staged messages; the driver's real run uses nccl).
+    3 ranks gives a middle rank with two neighbours; re-balancing runs every 3 steps."""
     env = dict(os.environ, FS_DIST_BACKEND="gloo", OMP_NUM_THREADS="2", FS_REBALANCE_EVERY="3")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--workload", "dam_break_2d_1M", "--no-cpu-baseline"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(29610 + ranks), "bench.py", "--gpus", str(ranks), "--steps", "8",
+           "--warmup", "3", "--workload", "dam_break_2d_1M", "--no-cpu-baseline"]
     env["FS_FORCE_DEVICE0"] = "1"
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["n_gpus"] == ranks and d["value"] > 0
     assert d["checks"]["particles_conserved"] and d["checks"]["protocol_violations"] == 0
 
 
