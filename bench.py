@@ -10,7 +10,6 @@ fs_timed_steps / fs_profile_*), bracketed by barrier + device sync, MAX over ran
 Prints ONE JSON line on rank 0 (contract fields + `roofline` + `cpu_baseline`).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys

@@ -1,4 +1,4 @@
-import sys, os, json
+import sys, os
 sys.path.insert(0, os.getcwd())
 import gpu_fluid_simulation_amd as g
 from gpu_fluid_simulation_amd import _abi

@@ -1,6 +1,6 @@
 """Single-rank slab engine vs plain engine on one GPU (same scene): what the fixed-capacity,
 device-resident-count design costs before any communication."""
-import os, sys, time, ctypes as C
+import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import gpu_fluid_simulation_amd as g
