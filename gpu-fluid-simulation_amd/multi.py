@@ -80,19 +80,19 @@ class Transport:
         self.send_right = torch.zeros(message_bytes, **kw)
         self.recv_left = torch.zeros(message_bytes, **kw)
         self.recv_right = torch.zeros(message_bytes, **kw)
+        # the four descriptors never change (fixed tensors, fixed peers): build them once
+        self.ops = []
+        if self.right is not None:
+            self.ops.append(dist.P2POp(dist.isend, self.send_right, self.right))
+            self.ops.append(dist.P2POp(dist.irecv, self.recv_right, self.right))
+        if self.left is not None:
+            self.ops.append(dist.P2POp(dist.isend, self.send_left, self.left))
+            self.ops.append(dist.P2POp(dist.irecv, self.recv_left, self.left))
 
     def exchange(self):
-        dist = self.dist
-        ops = []
-        if self.right is not None:
-            ops.append(dist.P2POp(dist.isend, self.send_right, self.right))
-            ops.append(dist.P2POp(dist.irecv, self.recv_right, self.right))
-        if self.left is not None:
-            ops.append(dist.P2POp(dist.isend, self.send_left, self.left))
-            ops.append(dist.P2POp(dist.irecv, self.recv_left, self.left))
-        if not ops:
+        if not self.ops:
             return
-        for req in dist.batch_isend_irecv(ops):
+        for req in self.dist.batch_isend_irecv(self.ops):
             req.wait()          # nccl: makes the current stream wait; gloo: blocks the host
 
 
