@@ -107,6 +107,7 @@ struct fs_sim {
     // cell-sorted snapshot the density/force passes read (Jacobi semantics).
     DevArray<float2> pos, vel, pos_s, vel_s, pred;
     DevArray<float> rho;
+    DevArray<float2> rho2;          // {density, RN(1/density)}: what the force pass gathers per neighbour
     DevArray<uint32_t> key;
     DevArray<fsd::u64> pairs;
     DevArray<uint32_t> sort_dirty;  // per-tile flags of the bitonic sort
@@ -120,6 +121,7 @@ struct fs_sim {
     DevArray<fs_particle> aos;      // lazily allocated 32-byte view
 
     fsd::ConstDiv div_2h3{}, div_h2{};   // exact constant divisions of the force pass, proven at create
+    bool rcp_ok = false, sqrt_ok = false; // rcp_rn_fast / sqrt_rn_fast proven on this device at create
 
     // slab (multi-GPU) mode
     bool slab = false;
@@ -142,7 +144,7 @@ struct fs_sim {
     hipEvent_t t0 = nullptr, t1 = nullptr;
 
     void release() {
-        pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release();
+        pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release(); rho2.release();
         key.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
         owned.release(); flags.release(); blockcnt.release(); blockoff.release(); slab_counters.release();
@@ -238,6 +240,9 @@ fsd::StepParams make_params(const fs_sim& s) {
     P.fast_math = s.opts.math_mode == FS_MATH_WGSL_ULP ? 1 : 0;
     P.div_2h3 = s.div_2h3;
     P.div_h2 = s.div_h2;
+    // div_by_rcp's guards assume dst <= ~h <= 2^19 (fs_device.h); FS_NO_SHAREDIV=1 keeps every `/` a true division
+    static const bool no_sharediv = getenv("FS_NO_SHAREDIV") != nullptr;
+    P.share_div = (!no_sharediv && s.div_2h3.ok && s.div_h2.ok && s.rcp_ok && s.sqrt_ok && P.h >= 0x1p-19f && P.h <= 0x1p19f) ? 1 : 0;
     P.col_origin = 0;
     P.own_lo = 0; P.own_hi = s.grid_w;
     P.grid_w_global = s.grid_w;
@@ -274,7 +279,20 @@ fs_status prove_force_constants(fs_sim* s) {
     const float h = s->settings.smoothing_radius;
     fs_status r = prove_constdiv(s->stream, s->counter.p + 1, 2.0f * h * h * h, &s->div_2h3);   // funcs.wgsl:119
     if (r != FS_OK) return r;
-    return prove_constdiv(s->stream, s->counter.p + 1, h * h, &s->div_h2);
+    r = prove_constdiv(s->stream, s->counter.p + 1, h * h, &s->div_h2);
+    if (r != FS_OK) return r;
+    // the lean reciprocal / square root of the shared-denominator path, over their whole ranges
+    s->rcp_ok = s->sqrt_ok = false;
+    if (getenv("FS_NO_SHAREDIV")) return FS_OK;
+    uint32_t bad[2] = {1, 1};
+    FS_HIP(hipMemsetAsync(s->counter.p + 1, 0, 2 * sizeof(uint32_t), s->stream));
+    fsd::launch_verify_unary(s->stream, 0, FS_RCP_LO, FS_RCP_HI, s->counter.p + 1);
+    fsd::launch_verify_unary(s->stream, 1, FS_SQRT_LO, FS_SQRT_HI, s->counter.p + 2);
+    FS_HIP(hipMemcpyAsync(bad, s->counter.p + 1, sizeof bad, hipMemcpyDeviceToHost, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    s->rcp_ok = bad[0] == 0;
+    s->sqrt_ok = bad[1] == 0;
+    return FS_OK;
 }
 
 fs_status ensure_events(fs_sim* s) {
@@ -330,9 +348,9 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, s->key.p, s->cs.p,
                         s->start_ref.p, s->work.p, s->counter.p, s->work_cap, counting);
     if (prof) FS_HIP(hipEventRecord(ev[3], st));
-    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p);
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p, s->rho2.p);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
-    fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho.p, s->cs.p, s->start_ref.p, s->pairs.p,
+    fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, s->pos.p, s->vel.p);
     if (prof) {
         FS_HIP(hipEventRecord(ev[5], st));
@@ -402,7 +420,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1));
@@ -676,7 +694,9 @@ fs_status fs_selftest_constdiv(int device, float c, float y, float lo, float hi,
 }
 
 /* Did the create-time proofs succeed for this handle's constants (2h^3, h^2)?  Bits 0 / 1. */
-int fs_constdiv_status(const fs_sim* s) { return s ? (s->div_2h3.ok ? 1 : 0) | (s->div_h2.ok ? 2 : 0) : 0; }
+int fs_constdiv_status(const fs_sim* s) {
+    return s ? (s->div_2h3.ok ? 1 : 0) | (s->div_h2.ok ? 2 : 0) | (s->rcp_ok ? 4 : 0) | (s->sqrt_ok ? 8 : 0) : 0;
+}
 
 /* ------------------------------------------------------------ slab mode */
 fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_config* cfg, fs_sim** out) {
@@ -727,7 +747,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->owned.alloc(cap)); FS_TRY(s->flags.alloc(cap));
@@ -841,9 +861,9 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
                              s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,
                              s->slab_counters.p, counting);
     if (ev) FS_HIP(hipEventRecord(ev[3], st));
-    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p);
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p, s->rho2.p);
     if (ev) FS_HIP(hipEventRecord(ev[4], st));
-    fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho.p, s->cs.p, s->start_ref.p, s->pairs.p,
+    fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, s->pos.p, s->vel.p);
     if (ev) { FS_HIP(hipEventRecord(ev[5], st)); s->prof_pending += 1; }
     FS_HIP(hipGetLastError());

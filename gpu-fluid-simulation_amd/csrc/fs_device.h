@@ -38,6 +38,7 @@ struct StepParams {
     int32_t ref_quirks;
     int32_t fast_math;         // FS_MATH_WGSL_ULP: native rcp/sqrt in the force pass (not bit-exact)
     ConstDiv div_2h3, div_h2;  // the two constant denominators of funcs.wgsl:119 (2h^3, h^2)
+    int32_t share_div;         // force pass: one true division per denominator + div_by_rcp (bit-identical)
     // --- slab (multi-GPU) mode: the local grid is a window of global cell columns -------------
     int32_t col_origin;        // global column of local column 0 (0 on a single GPU)
     uint32_t own_lo, own_hi;   // owned window [own_lo, own_hi) in GLOBAL columns
@@ -114,6 +115,49 @@ __device__ __forceinline__ float div_const_fast(float x, float c, float y) {
 __device__ __forceinline__ float div_const(const ConstDiv& K, float x) {
     return K.ok ? div_const_fast(x, K.c, K.y) : __fdiv_rn(x, K.c);     // K.ok is uniform (kernel argument)
 }
+
+// ---- exact quotients that share a denominator -------------------------------------------------
+// With y == RN(1/b) (ONE true division), RN(a/b) == fma(fma(-q0, b, a), y, q0), q0 = RN(a*y), for
+// every normal a, b as long as no intermediate leaves the normal range: power-of-two scaling is
+// exact and RN is sign-symmetric, so the claim only depends on the two mantissas, and all 2^46
+// mantissa pairs were enumerated on the GPU against hipcc's correctly rounded `/` — zero
+// mismatches (tools/div_markstein.hip x; profiles/r01_f_div_by_rcp_exhaustive.txt).  The residual
+// a - b*q0 is a multiple of 2^(ea-47), hence the callers' guards: 2^-20 <= b <= 2^20 and
+// 2^-60 <= |a| <= 2^60 or a == 0.  For a == -0 the quotient is +0 instead of -0; every use adds the
+// quotient (or a product with it) to an accumulator that starts at +0, where the sign of a zero
+// term cannot change the sum.  Anything outside the guards takes the true division.
+__device__ __forceinline__ float div_by_rcp(float a, float b, float y) {
+    const float q0 = a * y;
+    const float r = __builtin_fmaf(-q0, b, a);
+    return __builtin_fmaf(r, y, q0);
+}
+// RN(1/b) and RN(sqrt(x)) without the scaling / fix-up selects of hipcc's general expansions.  These
+// lean forms rest on the hardware approximation instructions, so the engine PROVES them when a
+// handle is created by enumerating every f32 of the range on the GPU against `1.0f / b` and
+// __builtin_sqrtf (k_verify_unary: 3.4e8 + 6.7e8 inputs, well under a millisecond); without the
+// proof the force pass keeps its true divisions.
+__device__ __forceinline__ float rcp_rn_fast(float b) {           // 2^-20 <= b <= 2^20
+    const float y = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y, 1.0f);
+    return __builtin_fmaf(e, y, y);
+}
+__device__ __forceinline__ float sqrt_rn_fast(float x) {          // 2^-40 <= x <= 2^40
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float hlf = 0.5f * __builtin_amdgcn_rsqf(x);
+    const float r = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(r, hlf, s);
+}
+#define FS_RCP_LO 0x1p-20f
+#define FS_RCP_HI 0x1p20f
+#define FS_SQRT_LO 0x1p-40f
+#define FS_SQRT_HI 0x1p40f
+
+// Range predicates as WAVE masks (one v_cmp into an SGPR pair each, combined on the scalar unit):
+// the caller only needs "does any active lane fall outside", never a per-lane flag.
+typedef unsigned long long wave_mask;
+__device__ __forceinline__ wave_mask wm(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ wave_mask rcp_num_lo_ok(float a) { return wm(fabsf(a) >= 0x1p-60f) | wm(a == 0.0f); }       // NaN: 0
+__device__ __forceinline__ wave_mask rcp_num_ok(float a) { return wm(fabsf(a) <= 0x1p60f) & rcp_num_lo_ok(a); }
 
 // ---- XCD-aware block index ---------------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one; MI355X guide, "Workgroup

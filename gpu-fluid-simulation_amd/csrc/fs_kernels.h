@@ -12,9 +12,9 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
                     void* work, uint32_t* counter, uint32_t work_cap, bool cs_ready = false);
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
-                    const uint32_t* start_ref, const u64* pairs, float* rho);
+                    const uint32_t* start_ref, const u64* pairs, float* rho, float2* rho2 /* {rho, RN(1/rho)} */);
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
-                  const float* rho, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
+                  const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out);
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
                        const float* rho, const uint32_t* key, void* out);
@@ -29,6 +29,8 @@ void launch_gradient_field(hipStream_t st, const unsigned char* image, uint32_t 
 // Exhaustive proof of fs_device.h div_const_fast over lo <= |x| <= hi (both signs).
 #define FS_CONSTDIV_MIN 8.67361737988403547e-19f   /* 2^-60 */
 void launch_verify_constdiv(hipStream_t st, float c, float y, float lo, float hi, uint32_t* mismatches);
+void launch_verify_unary(hipStream_t st, int which /* 0 rcp_rn_fast, 1 sqrt_rn_fast */, float lo, float hi,
+                         uint32_t* mismatches);
 size_t gap_entry_size();
 void launch_fill_gaps(hipStream_t st, uint32_t* cs, const void* work, const uint32_t* counter, uint32_t work_cap);
 

@@ -130,7 +130,8 @@ __device__ __forceinline__ float density_term(const StepParams& P, float h2, flo
 __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2* __restrict__ pred,
                                                       const uint32_t* __restrict__ cs,
                                                       const uint32_t* __restrict__ start_ref,
-                                                      const u64* __restrict__ pairs, float* __restrict__ rho_out) {
+                                                      const u64* __restrict__ pairs, float* __restrict__ rho_out,
+                                                      float2* __restrict__ rho2_out) {
     __shared__ float2 s_pred[3][NB_TILE];
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
@@ -182,7 +183,9 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
     }
     if (!live) return;
     rho = fmaxf(rho, 1.19209290e-07f);                          // funcs.wgsl:202
-    rho_out[i] = fmaxf(rho, 0.1f);                              // compute.wgsl:70
+    rho = fmaxf(rho, 0.1f);                                     // compute.wgsl:70
+    rho_out[i] = rho;
+    rho2_out[i] = make_float2(rho, __fdiv_rn(1.0f, rho));       // the force pass divides by neighbours' densities
 }
 
 // ---------------------------------------------------------- force + integrate
@@ -266,9 +269,50 @@ __device__ __forceinline__ ForceTerms force_terms(const StepParams& P, const flo
     return T;
 }
 
+// The same terms with ONE true division per denominator (1/dst, 1/nrho) and div_by_rcp() for the
+// seven quotients — bit-identical to force_terms<false> whenever `ok` comes back true (operands
+// inside the proven range, fs_device.h).  Straight-line: no PRNG path, no tiny-distance path;
+// those (and any out-of-range operand) clear the lane's bit in `good`, and the caller re-evaluates
+// the pair with the exact body for the whole wave when any active lane's bit is missing.
+__device__ __forceinline__ ForceTerms force_terms_shared(const StepParams& P, const float2 me, const float2 mv,
+                                                         float pressure, const float2 q, const float2 nv,
+                                                         const float2 nd /* {density, RN(1/density)} */, wave_mask& good) {
+    const float h = P.h;
+    const float nrho = nd.x, yrho = nd.y;
+    const float ox = q.x - me.x, oyv = q.y - me.y;
+    const float r2 = ox * ox + oyv * oyv;
+    // r2 >= 2^-40 excludes r2 == 0 (PRNG path), NaN and div_const's tiny range; r2 <= h*h because the
+    // scan admitted it, and the host only enables this path for h <= 2^19: the proven sqrt range
+    good = wm(r2 >= FS_SQRT_LO) & rcp_num_lo_ok(ox) & rcp_num_lo_ok(oyv) & wm(nrho <= FS_RCP_HI);   // nrho >= 0.1 (k_density)
+    const float dst = sqrt_rn_fast(r2);                                 // in [2^-20, ~h]
+    const float ydst = rcp_rn_fast(dst);
+    const float dx = div_by_rcp(ox, dst, ydst);
+    const float dy = div_by_rcp(oyv, dst, ydst);
+    const float npress = P.pressure_k * (nrho - P.rest_density);
+    const bool inside = dst <= h;
+    const float kern = inside ? (-(h - dst)) * P.spiky : 0.0f;
+    const float shared = (pressure + npress) * 0.5f;
+    const float apx = dx * kern * shared, apy = dy * kern * shared;
+    const float dvx = nv.x - mv.x, dvy = nv.y - mv.y;
+    good &= rcp_num_ok(apx) & rcp_num_ok(apy) & rcp_num_ok(dvx) & rcp_num_ok(dvy);
+    ForceTerms T;
+    T.px = div_by_rcp(apx, nrho, yrho);
+    T.py = div_by_rcp(apy, nrho, yrho);
+    // share_div implies both constant-division proofs succeeded (engine.hip)
+    const float a = div_const_fast(-(dst * dst * dst), P.div_2h3.c, P.div_2h3.y);
+    const float b = div_const_fast(dst * dst, P.div_h2.c, P.div_h2.y);
+    const float hq = div_by_rcp(h, 2.0f * dst, 0.5f * ydst);           // RN(1/(2 dst)) == RN(1/dst)/2 exactly
+    const float kv = inside ? P.visc_k * (a + b + hq - 1.0f) : 0.0f;
+    T.vx = div_by_rcp(dvx, nrho, yrho) * kv;
+    T.vy = div_by_rcp(dvy, nrho, yrho) * kv;
+    return T;
+}
+
 #ifndef NBF_TILE
 #define NBF_TILE 384
 #endif
+#define NBF_PAD 32u                      // force_sweep_masks reads up to 32 entries from a range start
+#define NBF_ROW (NBF_TILE + NBF_PAD)     // LDS row pitch of the staged candidates
 // staged candidates (predicted positions) per sweep row in k_force; vel/rho of the
                              // few in-radius neighbours are gathered in the heavy phase (staging them too cost
                              // occupancy and measured slower: the kernel is issue-bound, not latency-bound)
@@ -277,17 +321,20 @@ template <bool STAGED, bool FAST>
 __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges& R, const uint32_t* blo,
                                             uint32_t ii, const float2 me, const float2 mv, float pressure,
                                             const float2* __restrict__ pred, const float2* __restrict__ vel_s,
-                                            const float* __restrict__ rho, const float2 (*s_pred)[NBF_TILE],
+                                            const float2* __restrict__ rho2, const float2 (*s_pred)[NBF_ROW],
                                             unsigned short* s_list16, ForceAcc& A) {
     typedef typename std::conditional<STAGED, unsigned short, uint32_t>::type entry_t;
     entry_t* s_list = reinterpret_cast<entry_t*>(s_list16);
     constexpr uint32_t CAP = STAGED ? FORCE_CAP : FORCE_CAP / 2;     // same LDS bytes either way
     const uint32_t tid = threadIdx.x;
     uint32_t cnt = 0;
+    // plain registers (as an array the selects in the heavy phase become an indexed scratch load)
+    uint32_t blo0 = blo[0], blo1 = blo[1], blo2 = blo[2];
+    asm volatile("" : "+v"(blo0), "+v"(blo1), "+v"(blo2));
 #pragma unroll 1
     for (int r = 0; r <= 3; ++r) {
         // 4th trip only flushes; selects instead of dynamic indexing keep R/blo in registers
-        const uint32_t b0 = !STAGED ? 0u : r == 0 ? blo[0] : r == 1 ? blo[1] : r == 2 ? blo[2] : 0u;
+        const uint32_t b0 = !STAGED ? 0u : r == 0 ? blo0 : r == 1 ? blo1 : r == 2 ? blo2 : 0u;
         const uint32_t lo = (r == 0 ? R.lo[0] : r == 1 ? R.lo[1] : r == 2 ? R.lo[2] : 0u);
         const uint32_t hi = (r == 0 ? R.hi[0] : r == 1 ? R.hi[1] : r == 2 ? R.hi[2] : 0u);
         const float2* sp = s_pred[r < 3 ? r : 0] - (STAGED ? b0 : 0u);   // sp[k] is candidate k of this row
@@ -315,31 +362,59 @@ __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges
             const bool full = cnt == CAP && k < hi;
             const bool flush = __any(full) || r > 2;
             if (flush) {
-                // heavy phase: two neighbours per trip (independent divide chains in flight), terms
-                // added in list order
-                for (uint32_t e = 0; __any(e < cnt); e += 2u) {
-                    if (e < cnt) {
-                        const bool two = e + 1u < cnt;
-                        const uint32_t j0 = s_list[e * FS_BLOCK + tid];
-                        const uint32_t j1 = s_list[(two ? e + 1u : e) * FS_BLOCK + tid];
-                        float2 q0, q1;
-                        uint32_t g0, g1;
-                        if (STAGED) {
-                            const uint32_t r0 = j0 >> 14, o0 = j0 & 0x3FFFu, r1 = j1 >> 14, o1 = j1 & 0x3FFFu;
-                            q0 = s_pred[r0][o0]; q1 = s_pred[r1][o1];
-                            g0 = (r0 == 0 ? blo[0] : r0 == 1 ? blo[1] : blo[2]) + o0;
-                            g1 = (r1 == 0 ? blo[0] : r1 == 1 ? blo[1] : blo[2]) + o1;
-                        } else {
-                            g0 = j0; g1 = j1;
-                            q0 = pred[g0]; q1 = pred[g1];
+                if (FAST) {
+                    // heavy phase (native rcp/sqrt): two neighbours per trip, terms added in list order
+                    for (uint32_t e = 0; __any(e < cnt); e += 2u) {
+                        if (e < cnt) {
+                            const bool two = e + 1u < cnt;
+                            const uint32_t j0 = s_list[e * FS_BLOCK + tid];
+                            const uint32_t j1 = s_list[(two ? e + 1u : e) * FS_BLOCK + tid];
+                            float2 q0, q1;
+                            uint32_t g0, g1;
+                            if (STAGED) {
+                                const uint32_t r0 = j0 >> 14, o0 = j0 & 0x3FFFu, r1 = j1 >> 14, o1 = j1 & 0x3FFFu;
+                                q0 = s_pred[r0][o0]; q1 = s_pred[r1][o1];
+                                g0 = (r0 == 0 ? blo0 : r0 == 1 ? blo1 : blo2) + o0;
+                                g1 = (r1 == 0 ? blo0 : r1 == 1 ? blo1 : blo2) + o1;
+                            } else {
+                                g0 = j0; g1 = j1;
+                                q0 = pred[g0]; q1 = pred[g1];
+                            }
+                            const float2 v0 = vel_s[g0], v1 = vel_s[g1];
+                            const float d0 = rho2[g0].x, d1 = rho2[g1].x;
+                            const ForceTerms T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0, A.seed);
+                            uint32_t seed1 = A.seed;
+                            const ForceTerms T1 = force_terms<true>(P, me, mv, pressure, q1, v1, d1, seed1);
+                            A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
+                            if (two) { A.fpx += T1.px; A.fpy += T1.py; A.fvx += T1.vx; A.fvy += T1.vy; A.seed = seed1; }
                         }
-                        const float2 v0 = vel_s[g0], v1 = vel_s[g1];
-                        const float d0 = rho[g0], d1 = rho[g1];
-                        const ForceTerms T0 = force_terms<FAST>(P, me, mv, pressure, q0, v0, d0, A.seed);
-                        uint32_t seed1 = A.seed;
-                        const ForceTerms T1 = force_terms<FAST>(P, me, mv, pressure, q1, v1, d1, seed1);
-                        A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
-                        if (two) { A.fpx += T1.px; A.fpy += T1.py; A.fvx += T1.vx; A.fvy += T1.vy; A.seed = seed1; }
+                    }
+                } else {
+                    // heavy phase (bit-exact): one neighbour per trip — its two true divisions and seven
+                    // div_by_rcp tails are independent, so one pair already fills the pipeline and the
+                    // kernel keeps 8 waves/SIMD; the exact body runs only when a lane's operands fall
+                    // outside the proven range (wave-uniform, rare)
+                    for (uint32_t e = 0; __any(e < cnt); ++e) {
+                        if (e < cnt) {
+                            const uint32_t j0 = s_list[e * FS_BLOCK + tid];
+                            float2 q0;
+                            uint32_t g0;
+                            if (STAGED) {
+                                const uint32_t r0 = j0 >> 14, o0 = j0 & 0x3FFFu;
+                                q0 = s_pred[r0][o0];
+                                g0 = (r0 == 0 ? blo0 : r0 == 1 ? blo1 : blo2) + o0;
+                            } else {
+                                g0 = j0;
+                                q0 = pred[g0];
+                            }
+                            const float2 v0 = vel_s[g0];
+                            const float2 d0 = rho2[g0];
+                            wave_mask good = 0;
+                            ForceTerms T0;
+                            if (P.share_div) T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good);
+                            if (good != wm(true)) T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
+                            A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
+                        }
                     }
                 }
                 cnt = 0;
@@ -349,16 +424,86 @@ __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges
     }
 }
 
+// ---- mask sweep: the normal case (staged tiles, no row range of the wave longer than 32) ----------
+//   scan  — per sweep row one 32-bit pass mask in a register.  Per candidate: the LDS read, r2, and
+//           v_cmp_ngt + v_addc_co, which shifts `!(r2 > sqr_radius)` (compute.wgsl:202; true for NaN
+//           like the shader's test) into the mask — no branch, no LDS write.  Trip counts are
+//           wave-uniform (longest range of the wave, in fours); a lane masks off what lies past its
+//           own range afterwards, and the middle row clears the lane's own bit (`k != i`, :195).
+//   heavy — every lane walks its set bits, row 0, 1, 2, ascending = the reference visiting order, so
+//           the sums keep their association; all lanes stay busy until the longest list is done.
+__device__ __forceinline__ void shift_in_not_greater(uint32_t& mask, float r2, float lim) {
+    // !(lim < r2) == !(r2 > lim), NaN included; this operand order lets `lim` stay in an SGPR
+    asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
+}
+
+template <bool FAST>
+__device__ __forceinline__ void force_sweep_masks(const StepParams& P, const RowRanges& R, const uint32_t* blo,
+                                                  uint32_t ii, const float2 me, const float2 mv, float pressure,
+                                                  const float2* __restrict__ vel_s, const float2* __restrict__ rho2,
+                                                  const float2* s_flat /* [3][NBF_ROW] */, ForceAcc& A) {
+    uint32_t m[3], la[3];                    // masks (bit 31-t <=> candidate lo+t), flat LDS index of lo
+    const float lim = P.sqr_radius;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t len = R.hi[r] - R.lo[r];                           // <= 32 (caller)
+        la[r] = (uint32_t)r * NBF_ROW + (len ? R.lo[r] - blo[r] : 0u);
+        const float2* base = s_flat + la[r];
+        uint32_t mask = 0, t = 0;
+        for (; __any(t < len); t += 4u) {                                 // t is wave-uniform
+            const float2 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
+            const float2 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ox = qq[u].x - me.x, oyv = qq[u].y - me.y;
+                shift_in_not_greater(mask, ox * ox + oyv * oyv, lim);
+            }
+        }
+        // candidate t sits at bit (trips - 1 - t): left-align, keep the lane's own len candidates
+        mask = t ? mask << (32u - t) : 0u;
+        mask &= len ? 0xFFFFFFFFu << (32u - len) : 0u;
+        if (r == 1 && ii - R.lo[1] < len) mask &= ~(0x80000000u >> (ii - R.lo[1]));
+        m[r] = mask;
+    }
+    // plain registers: left as arrays the compiler turns the selects below into an indexed scratch load
+    uint32_t la0 = la[0], la1 = la[1], la2 = la[2], lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
+    asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));
+    while (__any((m[0] | m[1] | m[2]) != 0u)) {
+        if ((m[0] | m[1] | m[2]) != 0u) {
+            const bool s0 = m[0] != 0u, s1 = m[1] != 0u;
+            const uint32_t cur = s0 ? m[0] : s1 ? m[1] : m[2];
+            const uint32_t t = (uint32_t)__builtin_clz(cur);
+            const uint32_t bit = 0x80000000u >> t;
+            m[0] ^= s0 ? bit : 0u;
+            m[1] ^= (!s0 && s1) ? bit : 0u;
+            m[2] ^= (!s0 && !s1) ? bit : 0u;
+            const float2 q0 = s_flat[(s0 ? la0 : s1 ? la1 : la2) + t];
+            const uint32_t g0 = (s0 ? lo0 : s1 ? lo1 : lo2) + t;
+            const float2 v0 = vel_s[g0];
+            const float2 d0 = rho2[g0];                                  // {density, RN(1/density)}
+            ForceTerms T0;
+            if (FAST) {
+                T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
+            } else {
+                wave_mask good = 0;
+                if (P.share_div) T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good);
+                if (good != wm(true)) T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);   // rare, wave-uniform
+            }
+            A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
+        }
+    }
+}
+
 template <bool FAST>
 __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* __restrict__ pos_s,
                                                     const float2* __restrict__ vel_s,
-                                                    const float2* __restrict__ pred, const float* __restrict__ rho,
+                                                    const float2* __restrict__ pred, const float2* __restrict__ rho2,
                                                     const uint32_t* __restrict__ cs,
                                                     const uint32_t* __restrict__ start_ref,
                                                     const u64* __restrict__ pairs, const float2* __restrict__ tex,
                                                     float2* __restrict__ pos_out, float2* __restrict__ vel_out) {
     __shared__ unsigned short s_list[FORCE_CAP * FS_BLOCK];
-    __shared__ float2 s_pred[3][NBF_TILE];
+    __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
     const uint32_t n = P.n_live ? *P.n_live : P.n;
@@ -370,7 +515,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
     const float2 me = pred[ii];
     const float2 mv = vel_s[ii];
-    const float mrho = rho[ii];
+    const float mrho = rho2[ii].x;
     const float pressure = P.pressure_k * (mrho - P.rest_density);      // funcs.wgsl:152-154
     ForceAcc A;
     A.fpx = A.fpy = A.fvx = A.fvy = 0.0f;
@@ -397,9 +542,13 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
                 s_pred[r][j] = pred[blo[r] + j];
             }
         __syncthreads();
-        force_sweep<true, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho, s_pred, s_list, A);
+        const bool long_row = R.hi[0] - R.lo[0] > 32u || R.hi[1] - R.lo[1] > 32u || R.hi[2] - R.lo[2] > 32u;
+        if (!__any(long_row))
+            force_sweep_masks<FAST>(P, R, blo, ii, me, mv, pressure, vel_s, rho2, &s_pred[0][0], A);
+        else
+            force_sweep<true, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, s_pred, s_list, A);
     } else {
-        force_sweep<false, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho, s_pred, s_list, A);
+        force_sweep<false, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, s_pred, s_list, A);
     }
     if (!live) return;
     const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
@@ -507,6 +656,29 @@ void launch_verify_constdiv(hipStream_t st, float c, float y, float lo, float hi
     hipLaunchKernelGGL(k_verify_constdiv, dim3(256 * 32), dim3(FS_BLOCK), 0, st, c, y, lb, hb, mismatches);
 }
 
+// ------------------------------------------------------- proof kernel for rcp_rn_fast / sqrt_rn_fast
+// Enumerates EVERY f32 in [lo, hi] (bit patterns; positive) and counts inputs whose lean result
+// differs bitwise from the correctly rounded 1.0f / x (which == 0) or __builtin_sqrtf(x) (which == 1).
+__global__ __launch_bounds__(FS_BLOCK) void k_verify_unary(int which, uint32_t lo_bits, uint32_t hi_bits,
+                                                           uint32_t* __restrict__ mismatches) {
+    const uint32_t total_threads = gridDim.x * FS_BLOCK;
+    uint32_t bad = 0;
+    for (uint64_t b = (uint64_t)lo_bits + blockIdx.x * FS_BLOCK + threadIdx.x; b <= (uint64_t)hi_bits; b += total_threads) {
+        const float x = __uint_as_float((uint32_t)b);
+        const uint32_t got = __float_as_uint(which == 0 ? rcp_rn_fast(x) : sqrt_rn_fast(x));
+        const uint32_t ref = __float_as_uint(which == 0 ? __fdiv_rn(1.0f, x) : sqrt_rn(x));
+        bad += got != ref ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+void launch_verify_unary(hipStream_t st, int which, float lo, float hi, uint32_t* mismatches) {
+    uint32_t lb, hb;
+    memcpy(&lb, &lo, 4);
+    memcpy(&hb, &hi, 4);
+    hipLaunchKernelGGL(k_verify_unary, dim3(256 * 32), dim3(FS_BLOCK), 0, st, which, lb, hb, mismatches);
+}
+
 // ------------------------------------------------------- density-splat image (fluid_shader.wgsl:27-102)
 __device__ __forceinline__ float smoothstep_f(float a, float b, float x) {
     float t = __fdiv_rn(x - a, b - a);
@@ -588,20 +760,20 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
 }
 
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
-                    const uint32_t* start_ref, const u64* pairs, float* rho) {
+                    const uint32_t* start_ref, const u64* pairs, float* rho, float2* rho2) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
-    hipLaunchKernelGGL(k_density, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, rho);
+    hipLaunchKernelGGL(k_density, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, rho, rho2);
 }
 
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
-                  const float* rho, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
+                  const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
     if (P.fast_math)
-        hipLaunchKernelGGL(k_force<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho, cs,
+        hipLaunchKernelGGL(k_force<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
                            start_ref, pairs, tex, pos_out, vel_out);
     else
-        hipLaunchKernelGGL(k_force<false>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho, cs,
+        hipLaunchKernelGGL(k_force<false>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
                            start_ref, pairs, tex, pos_out, vel_out);
 }
 

@@ -329,12 +329,19 @@ void* fs_buffer_device_ptr(const fs_buffer* buf); /* bind_group() equivalent (sr
 void fs_buffer_destroy(fs_buffer* buf);
 
 /* ------------------------------------------------------------- self-tests */
-/* The force pass divides by two loop-invariant constants (2h^3, h^2; funcs.wgsl:119).  At create
- * time the engine PROVES, by enumerating on the GPU every f32 numerator the kernel can feed it
- * (2^-60 <= |x| <= c, both signs; smaller ones take the true division), that a 3-instruction
- * form is bit-identical to the IEEE division for the handle's constants; only then is it used.
- * fs_selftest_constdiv exposes that enumeration (mismatch count for constant c, reciprocal y and
- * range [lo, hi]); fs_constdiv_status returns bit 0 / bit 1 = proof succeeded for 2h^3 / h^2. */
+/* Bit-exact parity makes the force pass divide-bound; three identities let it keep IEEE results
+ * with far fewer instructions, and each is PROVEN by enumeration on the GPU before it is used:
+ *  - division by the two loop-invariant constants (2h^3, h^2; funcs.wgsl:119) as a 3-instruction
+ *    form: every f32 numerator the kernel can feed it (2^-60 <= |x| <= c, both signs) is checked
+ *    against `/` for the handle's constants when the handle is created;
+ *  - RN(1/b) on [2^-20, 2^20] as v_rcp_f32 + one Newton step and RN(sqrt(x)) on [2^-40, 2^40] as
+ *    v_sqrt_f32 + one Newton/Markstein correction: every f32 of both ranges is checked at create;
+ *  - a/b from y = RN(1/b) as q0 = a*y, q = fma(fma(-q0, b, a), y, q0): holds for all 2^46 mantissa
+ *    pairs (tools/div_markstein.hip, profiles/r01_f_div_by_rcp_exhaustive.txt), used inside range
+ *    guards; operands outside the guards take the true division.
+ * fs_selftest_constdiv exposes the first enumeration (mismatch count for constant c, reciprocal y,
+ * range [lo, hi]); fs_constdiv_status returns bit 0 / 1 = proof succeeded for 2h^3 / h^2, bit 2 / 3
+ * = for the lean reciprocal / square root (15 = everything in use). */
 fs_status fs_selftest_constdiv(int device, float c, float y, float lo, float hi, uint32_t* mismatches);
 int fs_constdiv_status(const fs_sim* sim);
 

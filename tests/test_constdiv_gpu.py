@@ -41,3 +41,5 @@ def test_constant_division_proofs(fs):
     status = fs.load_library().fs_constdiv_status(sim._h)
     assert bool(status & 1) == (results[(float(f(0.2)), "2h3")] == 0)
     assert bool(status & 2) == (results[(float(f(0.2)), "h2")] == 0)
+    # bits 2 / 3: the lean reciprocal and square root were proven over their whole ranges on this device
+    assert status & 4 and status & 8, f"rcp/sqrt proofs failed on this device (status {status})"

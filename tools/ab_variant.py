@@ -8,8 +8,10 @@ if variant != "default":
 n = 1 << 24
 st, off, tick = g.dam_break_2d(n)
 sim = g.FluidSimulation(st, device=0, initial_offset=off)
-for _ in range(5): sim.tick(tick)
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+for _ in range(warm): sim.tick(tick)
 sim.sync(); sim.profile(True); sim.profile_read(True)
-ms = sim.timed_steps(tick, 20)
+ms = sim.timed_steps(tick, steps)
 p, k = sim.profile_read(True)
-print(variant, round(ms/20, 4), {a: round(b/20, 4) for a, b in p.items()})
+print(variant, f"steps {warm}-{warm+steps}", round(ms/steps, 4), {a: round(b/steps, 4) for a, b in p.items()})
