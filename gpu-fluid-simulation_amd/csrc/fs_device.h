@@ -199,9 +199,18 @@ __device__ __forceinline__ bool block_tile_bounds(const RowRanges& R, uint32_t* 
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
+        // Lanes hold consecutive sorted particles, so their cell ids — and with them cs[id_lo] and
+        // cs[id_hi] of one sweep row — are non-decreasing in lane order (quirk_lo_fix keeps that:
+        // lo_fix <= cs[first cell + 1] <= any non-zero start).  Min lo / max hi over the lanes that
+        // have candidates are therefore the FIRST such lane's lo and the LAST one's hi: a ballot
+        // and two readlanes instead of twelve shuffle steps.
         const bool has = R.lo[r] < R.hi[r];
-        const uint32_t mn = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
-        const uint32_t mx = wave_max_u32(has ? R.hi[r] : 0u);
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(has);
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        if (hm) {
+            mn = (uint32_t)__builtin_amdgcn_readlane((int)R.lo[r], __builtin_ctzll(hm));
+            mx = (uint32_t)__builtin_amdgcn_readlane((int)R.hi[r], 63 - __builtin_clzll(hm));
+        }
         if (lane == 0) { s_red[(r * 2) * 4 + w] = mn; s_red[(r * 2 + 1) * 4 + w] = mx; }
     }
     __syncthreads();
