@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -30,6 +31,7 @@ struct Params3 {
     float gx, gy, gz;
     uint32_t frame;
     ConstDiv div_2h3, div_h2;    // exact constant divisions, proven at create (fs_device.h div_const)
+    int32_t share_div;           // one reciprocal per denominator + div_by_rcp in the force pass (fs_device.h)
 };
 
 #define B3 256
@@ -209,15 +211,149 @@ __device__ __forceinline__ Terms3 terms3(const Params3& P, float4 me, float4 mv,
     return T;
 }
 
-// Same two-phase structure as the 2D k_force: scan -> per-lane list in LDS -> dense heavy phase.
-// (Plane-wise LDS staging of the candidates was measured SLOWER here — 3.2 vs 2.6 ms at 8 M: with ~216
-// candidates and ~33 in-radius pairs per particle the kernel is divide-bound and the extra barriers /
-// LDS only cost occupancy — so the scan reads the L1/L2-resident rows directly.)
+// The same terms with one reciprocal per denominator (dst, neighbour density) and div_by_rcp() for
+// the ten quotients — bit-identical to terms3() for every lane whose bit stays set in `good`
+// (fs_device.h: the proven ranges).  No PRNG / tiny-distance path: those lanes clear their bit and
+// the caller re-evaluates the pair with terms3() for the whole wave.
+__device__ __forceinline__ Terms3 terms3_shared(const Params3& P, float4 me, float4 mv, float pressure, float4 q,
+                                                float4 nv, wave_mask& good) {
+    const float h = P.h;
+    const float ox = q.x - me.x, oy = q.y - me.y, oz = q.z - me.z;
+    const float r2 = ox * ox + oy * oy + oz * oz;
+    const float nrho = q.w;                                            // >= 0.1 (k3_density)
+    good = wm(r2 >= FS_SQRT_LO) & rcp_num_lo_ok(ox) & rcp_num_lo_ok(oy) & rcp_num_lo_ok(oz) & wm(nrho <= FS_RCP_HI);
+    const float dst = sqrt_rn_fast(r2);                                // r2 <= h*h: the scan admitted it
+    const float ydst = rcp_rn_fast(dst);
+    const float yrho = rcp_rn_fast(nrho);
+    const float dx = div_by_rcp(ox, dst, ydst), dy = div_by_rcp(oy, dst, ydst), dz = div_by_rcp(oz, dst, ydst);
+    const float npress = P.pressure_k * (nrho - P.rest_density);
+    const bool inside = dst <= h;
+    const float kern = inside ? (-(h - dst)) * P.spiky : 0.0f;
+    const float shared = (pressure + npress) * 0.5f;
+    const float apx = dx * kern * shared, apy = dy * kern * shared, apz = dz * kern * shared;
+    const float dvx = nv.x - mv.x, dvy = nv.y - mv.y, dvz = nv.z - mv.z;
+    good &= rcp_num_ok(apx) & rcp_num_ok(apy) & rcp_num_ok(apz) & rcp_num_ok(dvx) & rcp_num_ok(dvy) & rcp_num_ok(dvz);
+    const float a = div_const_fast(-(dst * dst * dst), P.div_2h3.c, P.div_2h3.y);   // share_div implies both proofs
+    const float b = div_const_fast(dst * dst, P.div_h2.c, P.div_h2.y);
+    const float hq = div_by_rcp(h, 2.0f * dst, 0.5f * ydst);
+    const float kv = inside ? P.visc_k * (a + b + hq - 1.0f) : 0.0f;
+    Terms3 T;
+    T.px = div_by_rcp(apx, nrho, yrho); T.py = div_by_rcp(apy, nrho, yrho); T.pz = div_by_rcp(apz, nrho, yrho);
+    T.vx = div_by_rcp(dvx, nrho, yrho) * kv; T.vy = div_by_rcp(dvy, nrho, yrho) * kv; T.vz = div_by_rcp(dvz, nrho, yrho) * kv;
+    return T;
+}
+
+__device__ __forceinline__ void acc3_add(Acc3& A, const Terms3& T) {
+    A.px += T.px; A.py += T.py; A.pz += T.pz; A.vx += T.vx; A.vy += T.vy; A.vz += T.vz;
+}
+
+__device__ __forceinline__ Terms3 pair3(const Params3& P, float4 me, float4 mv, float pressure, float4 q, float4 nv,
+                                        Acc3& A) {
+    wave_mask good = 0;
+    Terms3 T;
+    if (P.share_div) T = terms3_shared(P, me, mv, pressure, q, nv, good);
+    if (good != wm(true)) T = terms3(P, me, mv, pressure, q, nv, A.seed);      // rare, wave-uniform
+    return T;
+}
+
+// General sweep of three rows (one z-plane): scan -> per-lane list in LDS -> dense heavy phase, reading
+// the L1/L2-resident rows directly.  Used when the plane's rows do not fit the tile or a range is long.
+__device__ __forceinline__ void sweep3_list(const Params3& P, const RowRanges& R, uint32_t ii, float4 me, float4 mv,
+                                            float pressure, const float4* __restrict__ pred,
+                                            const float4* __restrict__ vel_s, uint32_t* s_list, Acc3& A) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t cnt = 0;
+#pragma unroll 1
+    for (int r = 0; r <= 3; ++r) {
+        const uint32_t lo = r == 0 ? R.lo[0] : r == 1 ? R.lo[1] : r == 2 ? R.lo[2] : 0u;
+        const uint32_t hi = r == 0 ? R.hi[0] : r == 1 ? R.hi[1] : r == 2 ? R.hi[2] : 0u;
+        uint32_t k = lo;
+        for (;;) {
+            for (; k < hi && cnt < CAP3; ++k) {
+                const float4 q = pred[k];
+                const float ox = q.x - me.x, oy = q.y - me.y, oz = q.z - me.z;
+                const float r2 = ox * ox + oy * oy + oz * oz;
+                if (k != ii && !(r2 > P.h2)) { s_list[cnt * B3 + tid] = k; ++cnt; }
+            }
+            const bool full = cnt == CAP3 && k < hi;
+            if (__any(full) || r == 3) {
+                for (uint32_t e = 0; __any(e < cnt); ++e) {
+                    if (e < cnt) {
+                        const uint32_t j0 = s_list[e * B3 + tid];
+                        acc3_add(A, pair3(P, me, mv, pressure, pred[j0], vel_s[j0], A));
+                    }
+                }
+                cnt = 0;
+            }
+            if (!__any(k < hi)) break;
+        }
+    }
+}
+
+#define TILE3_PAD 32u
+#define TILE3_ROW (TILE3 + TILE3_PAD)
+
+// Mask sweep of one staged z-plane (see kernels_step.hip force_sweep_masks): per row a 32-bit pass
+// mask built with v_cmp + v_addc_co per candidate, then every lane walks its set bits row 0, 1, 2,
+// ascending — the oracle's visiting order.  `self_row`: the lane's own particle sits in row 1 of
+// the middle plane and is skipped (k != i).
+__device__ __forceinline__ void shift_in_not_greater3(uint32_t& mask, float r2, float lim) {
+    asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
+}
+
+__device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& R, const uint32_t* blo, bool self_plane,
+                                             uint32_t ii, float4 me, float4 mv, float pressure,
+                                             const float4* __restrict__ vel_s, const float4* s_flat, Acc3& A) {
+    uint32_t m[3], la[3];
+    const float lim = P.h2;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t len = R.hi[r] - R.lo[r];                           // <= 32 (caller)
+        la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
+        const float4* base = s_flat + la[r];
+        uint32_t mask = 0, t = 0;
+        for (; __any(t < len); t += 4u) {                                 // t is wave-uniform
+            const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
+            const float4 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
+                shift_in_not_greater3(mask, ox * ox + oy * oy + oz * oz, lim);
+            }
+        }
+        mask = t ? mask << (32u - t) : 0u;
+        mask &= len ? 0xFFFFFFFFu << (32u - len) : 0u;
+        if (r == 1 && self_plane && ii - R.lo[1] < len) mask &= ~(0x80000000u >> (ii - R.lo[1]));
+        m[r] = mask;
+    }
+    uint32_t la0 = la[0], la1 = la[1], la2 = la[2], lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
+    asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));   // keep them registers
+    while (__any((m[0] | m[1] | m[2]) != 0u)) {
+        if ((m[0] | m[1] | m[2]) != 0u) {
+            const bool s0 = m[0] != 0u, s1 = m[1] != 0u;
+            const uint32_t cur = s0 ? m[0] : s1 ? m[1] : m[2];
+            const uint32_t t = (uint32_t)__builtin_clz(cur);
+            const uint32_t bit = 0x80000000u >> t;
+            m[0] ^= s0 ? bit : 0u;
+            m[1] ^= (!s0 && s1) ? bit : 0u;
+            m[2] ^= (!s0 && !s1) ? bit : 0u;
+            const float4 q0 = s_flat[(s0 ? la0 : s1 ? la1 : la2) + t];
+            const uint32_t g0 = (s0 ? lo0 : s1 ? lo1 : lo2) + t;
+            acc3_add(A, pair3(P, me, mv, pressure, q0, vel_s[g0], A));
+        }
+    }
+}
+
+// The 27-cell sweep runs plane by plane (z outer).  Per plane the workgroup's three row ranges are staged
+// into LDS (as in k3_density) and swept with register pass-masks; planes whose rows do not fit the
+// tile, or that hold a range longer than 32, take the list sweep over global memory.
 __global__ __launch_bounds__(B3) void k3_force(Params3 P, const float4* __restrict__ pos_s,
                                                const float4* __restrict__ vel_s, const float4* __restrict__ pred,
                                                const uint32_t* __restrict__ cs, float4* __restrict__ pos_out,
                                                float4* __restrict__ vel_out) {
-    __shared__ uint32_t s_list[CAP3 * B3];
+    // one buffer: the staged plane (3 x TILE3_ROW float4) or, on the general path, the neighbour list
+    __shared__ float4 s_buf[3 * TILE3_ROW > CAP3 * B3 / 4 ? 3 * TILE3_ROW : CAP3 * B3 / 4];
+    __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * B3 + tid;
     const bool live = i < P.n;
@@ -231,40 +367,35 @@ __global__ __launch_bounds__(B3) void k3_force(Params3 P, const float4* __restri
     A.seed = ii * 12u + P.frame * 69u;
     uint32_t cx, cy, cz;
     cell3(P, me, &cx, &cy, &cz);
-    uint32_t cnt = 0;
+    uint32_t lo9[9], hi9[9];        // all 18 cell-start lookups up front: independent loads, one latency
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        lo9[j] = 0; hi9[j] = 0;
+        if (live && !row3(P, cs, cx, cy, cz, j, &lo9[j], &hi9[j])) { lo9[j] = 0; hi9[j] = 0; }
+    }
 #pragma unroll 1
-    for (int j = 0; j <= 9; ++j) {
-        uint32_t lo = 0, hi = 0;
-        if (live && j < 9) { if (!row3(P, cs, cx, cy, cz, j, &lo, &hi)) { lo = 0; hi = 0; } }
-        uint32_t k = lo;
-        for (;;) {
-            for (; k < hi && cnt < CAP3; ++k) {
-                const float4 q = pred[k];
-                const float ox = q.x - me.x, oy = q.y - me.y, oz = q.z - me.z;
-                const float r2 = ox * ox + oy * oy + oz * oz;
-                if (k != ii && !(r2 > P.h2)) { s_list[cnt * B3 + tid] = k; ++cnt; }
-            }
-            const bool full = cnt == CAP3 && k < hi;
-            if (__any(full) || j == 9) {
-                for (uint32_t e = 0; __any(e < cnt); e += 2u) {
-                    if (e < cnt) {
-                        const bool two = e + 1u < cnt;
-                        const uint32_t j0 = s_list[e * B3 + tid], j1 = s_list[(two ? e + 1u : e) * B3 + tid];
-                        const float4 q0 = pred[j0], q1 = pred[j1], v0 = vel_s[j0], v1 = vel_s[j1];
-                        const Terms3 T0 = terms3(P, me, mv, pressure, q0, v0, A.seed);
-                        uint32_t seed1 = A.seed;
-                        const Terms3 T1 = terms3(P, me, mv, pressure, q1, v1, seed1);
-                        A.px += T0.px; A.py += T0.py; A.pz += T0.pz; A.vx += T0.vx; A.vy += T0.vy; A.vz += T0.vz;
-                        if (two) {
-                            A.px += T1.px; A.py += T1.py; A.pz += T1.pz; A.vx += T1.vx; A.vy += T1.vy; A.vz += T1.vz;
-                            A.seed = seed1;
-                        }
-                    }
-                }
-                cnt = 0;
-            }
-            if (!__any(k < hi)) break;
+    for (int plane = 0; plane < 3; ++plane) {
+        RowRanges R;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            R.lo[r] = plane == 0 ? lo9[r] : plane == 1 ? lo9[3 + r] : lo9[6 + r];
+            R.hi[r] = plane == 0 ? hi9[r] : plane == 1 ? hi9[3 + r] : hi9[6 + r];
         }
+        uint32_t blo[3], bhi[3];
+        const bool fit = block_tile_bounds(R, s_red, blo, bhi, TILE3);
+        const bool long_row = R.hi[0] - R.lo[0] > 32u || R.hi[1] - R.lo[1] > 32u || R.hi[2] - R.lo[2] > 32u;
+        // block-uniform choice (the two paths use s_buf differently): any long row anywhere -> list path
+        const bool masks = fit && !__syncthreads_or(long_row);
+        if (masks) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                for (uint32_t j = tid; j < bhi[r] - blo[r]; j += B3) s_buf[r * TILE3_ROW + j] = pred[blo[r] + j];
+            __syncthreads();
+            sweep3_masks(P, R, blo, plane == 1, ii, me, mv, pressure, vel_s, s_buf, A);
+        } else {
+            sweep3_list(P, R, ii, me, mv, pressure, pred, vel_s, reinterpret_cast<uint32_t*>(s_buf), A);
+        }
+        __syncthreads();     // the next plane reuses s_buf / s_red
     }
     if (!live) return;
     float4 v = mv, p = pos_s[i];
@@ -361,6 +492,7 @@ struct fs_sim3 {
     double ms[FS_PASS_COUNT] = {};
     uint64_t steps = 0;
     fsd::ConstDiv div_2h3{}, div_h2{};
+    bool share_div = false;      // all create-time proofs of the shared-denominator path succeeded
     void release() {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); key.release(); cs.release();
         counter.release(); dirty.release(); pairs.release(); work.release(); aos.release();
@@ -408,6 +540,7 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     P.frame = s->tick;
     P.div_2h3 = s->div_2h3;
     P.div_h2 = s->div_h2;
+    P.share_div = s->share_div ? 1 : 0;
     hipStream_t st = s->stream;
     hipEvent_t* ev = nullptr;
     if (s->profile) {
@@ -496,6 +629,18 @@ fs_status fs3_create(const fs3_settings* st, int device, fs_vec3 off, fs_sim3** 
         T3(hipMemcpyAsync(&bad, s->counter.p + 1, 4, hipMemcpyDeviceToHost, s->stream));
         T3(hipStreamSynchronize(s->stream));
         K.ok = bad == 0 ? 1 : 0;
+    }
+    {   // lean reciprocal / square root of the shared-denominator path, over their whole ranges (engine.hip)
+        uint32_t bad[2] = {1, 1};
+        const float hh = st->smoothing_radius;
+        if (!getenv("FS_NO_SHAREDIV")) {
+            T3(hipMemsetAsync(s->counter.p + 1, 0, 8, s->stream));
+            fsd::launch_verify_unary(s->stream, 0, FS_RCP_LO, FS_RCP_HI, s->counter.p + 1);
+            fsd::launch_verify_unary(s->stream, 1, FS_SQRT_LO, FS_SQRT_HI, s->counter.p + 2);
+            T3(hipMemcpyAsync(bad, s->counter.p + 1, 8, hipMemcpyDeviceToHost, s->stream));
+            T3(hipStreamSynchronize(s->stream));
+        }
+        s->share_div = bad[0] == 0 && bad[1] == 0 && s->div_2h3.ok && s->div_h2.ok && hh >= 0x1p-19f && hh <= 0x1p19f;
     }
 #undef T3
     *out = s;
