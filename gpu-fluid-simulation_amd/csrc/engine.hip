@@ -70,6 +70,7 @@ void grid_dims(const fs_settings& s, uint32_t* gw, uint32_t* gh) {
 
 bool settings_valid(const fs_settings& s, std::string* why) {
     if (s.particle_count <= 1) { *why = "particle_count <= 1 (reference panics in ilog2, src/simulation.rs:323-324)"; return false; }
+    if (s.particle_count > (1u << 28)) { *why = "particle_count > 2^28 (the kernels use 32-bit byte offsets into 8-byte arrays)"; return false; }
     if (!(s.smoothing_radius > 0.0f) || !std::isfinite(s.smoothing_radius)) { *why = "smoothing_radius must be finite and > 0"; return false; }
     if (!(s.size.x > 0.0f) || !(s.size.y > 0.0f) || !std::isfinite(s.size.x) || !std::isfinite(s.size.y)) { *why = "size must be finite and > 0"; return false; }
     if (!std::isfinite(s.particle_spacing)) { *why = "particle_spacing must be finite"; return false; }
@@ -404,6 +405,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     s->device = opts->device;
     s->n = settings->particle_count;
     s->capacity = opts->capacity > s->n ? opts->capacity : s->n;
+    if (s->capacity > (1u << 28)) { delete s; return fail(FS_ERR_INVALID, "capacity > 2^28"); }
     grid_dims(*settings, &s->grid_w, &s->grid_h);
     s->ncell = s->grid_w * s->grid_h;
     s->work_cap = s->ncell / 16u + 1024u;
@@ -711,6 +713,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     if (cfg->max_cols < cfg->own_hi - cfg->own_lo) return fail(FS_ERR_INVALID, "max_cols < window");
     if (cfg->capacity <= 2 * cfg->recv_capacity || cfg->recv_capacity == 0)
         return fail(FS_ERR_INVALID, "capacity must exceed 2*recv_capacity");
+    if (cfg->capacity > (1u << 28)) return fail(FS_ERR_INVALID, "capacity > 2^28");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(FS_ERR_DEVICE, "no HIP device: the engine has no CPU fallback");

@@ -466,7 +466,7 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
         m[r] = mask;
     }
     // plain registers: left as arrays the compiler turns the selects below into an indexed scratch load
-    uint32_t la0 = la[0], la1 = la[1], la2 = la[2], lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
+    uint32_t la0 = la[0] << 3, la1 = la[1] << 3, la2 = la[2] << 3, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
     asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));
     while (__any((m[0] | m[1] | m[2]) != 0u)) {
         if ((m[0] | m[1] | m[2]) != 0u) {
@@ -477,10 +477,13 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
             m[0] ^= s0 ? bit : 0u;
             m[1] ^= (!s0 && s1) ? bit : 0u;
             m[2] ^= (!s0 && !s1) ? bit : 0u;
-            const float2 q0 = s_flat[(s0 ? la0 : s1 ? la1 : la2) + t];
+            const float2 q0 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(s_flat) +
+                                                               ((s0 ? la0 : s1 ? la1 : la2) + (t << 3)));   // la* in bytes
             const uint32_t g0 = (s0 ? lo0 : s1 ? lo1 : lo2) + t;
-            const float2 v0 = vel_s[g0];
-            const float2 d0 = rho2[g0];                                  // {density, RN(1/density)}
+            // both arrays hold 8-B elements: one 32-bit byte offset from the two SGPR bases (n < 2^29)
+            const uint32_t off = g0 << 3;
+            const float2 v0 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vel_s) + off);
+            const float2 d0 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rho2) + off);   // {density, RN(1/density)}
             ForceTerms T0;
             if (FAST) {
                 T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);

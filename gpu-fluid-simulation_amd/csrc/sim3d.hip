@@ -326,7 +326,7 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& 
         if (r == 1 && self_plane && ii - R.lo[1] < len) mask &= ~(0x80000000u >> (ii - R.lo[1]));
         m[r] = mask;
     }
-    uint32_t la0 = la[0], la1 = la[1], la2 = la[2], lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
+    uint32_t la0 = la[0] << 4, la1 = la[1] << 4, la2 = la[2] << 4, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
     asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));   // keep them registers
     while (__any((m[0] | m[1] | m[2]) != 0u)) {
         if ((m[0] | m[1] | m[2]) != 0u) {
@@ -337,9 +337,12 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& 
             m[0] ^= s0 ? bit : 0u;
             m[1] ^= (!s0 && s1) ? bit : 0u;
             m[2] ^= (!s0 && !s1) ? bit : 0u;
-            const float4 q0 = s_flat[(s0 ? la0 : s1 ? la1 : la2) + t];
+            const float4 q0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_flat) +
+                                                               ((s0 ? la0 : s1 ? la1 : la2) + (t << 4)));   // la* in bytes
             const uint32_t g0 = (s0 ? lo0 : s1 ? lo1 : lo2) + t;
-            acc3_add(A, pair3(P, me, mv, pressure, q0, vel_s[g0], A));
+            // 32-bit byte offset from the SGPR base (n <= 2^28) instead of 64-bit address arithmetic
+            const float4 v0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + (g0 << 4));
+            acc3_add(A, pair3(P, me, mv, pressure, q0, v0, A));
         }
     }
 }
@@ -578,6 +581,7 @@ fs_status fs3_create(const fs3_settings* st, int device, fs_vec3 off, fs_sim3** 
     if (!st || !out) return fail3(FS_ERR_INVALID, "null argument");
     *out = nullptr;
     if (st->particle_count <= 1) return fail3(FS_ERR_INVALID, "particle_count <= 1");
+    if (st->particle_count > (1u << 28)) return fail3(FS_ERR_INVALID, "particle_count > 2^28 (32-bit byte offsets)");
     if (!(st->smoothing_radius > 0.0f) || !(st->size.x > 0) || !(st->size.y > 0) || !(st->size.z > 0))
         return fail3(FS_ERR_INVALID, "bad settings");
     const uint32_t side = (uint32_t)std::llround(std::cbrt((double)st->particle_count));
