@@ -145,7 +145,8 @@ typedef struct fs_buffer fs_buffer; /* opaque: ResizableBuffer<T> */
 /* ------------------------------------------------------------- lifecycle */
 /* FluidSimulation::new (src/simulation.rs:139): builds the reference lattice
  * (:147-163), zeroed start_indices (:204-209) and force field (:213-218).
- * device = HIP ordinal.  N <= 1 -> FS_ERR_INVALID (reference: ilog2(0) panic). */
+ * device = HIP ordinal.  N <= 1 -> FS_ERR_INVALID (reference: ilog2(0) panic);
+ * N (or options.capacity) > 2^28 -> FS_ERR_INVALID (32-bit byte offsets in the kernels). */
 fs_status fs_create(const fs_settings* settings, int device, fs_sim** out);
 fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_sim** out);
 void fs_options_default(fs_options* opts);

@@ -403,3 +403,72 @@ def test_random_configurations(fs, orc, case):
             assert_particles_equal(sim.download_particles(), ref.particles(), f"random case {case} mode {mode} step {s}")
             assert np.array_equal(sim.download_start_indices(), ref.start_indices())
         sim.close(); ref.close()
+
+
+# ---- operands at and beyond the guards of the shared-denominator quotients ----------
+# The force pass forms a/b from one reciprocal only inside proven ranges; everything else must take the
+# true-division body.  These scenes put numerators and denominators on both sides of every guard.
+@pytest.mark.parametrize("case", ["tiny_offsets", "tiny_velocities", "huge_velocities", "inf_velocity",
+                                  "zero_aligned", "huge_pressure", "near_zero_coordinates"])
+def test_force_quotient_guards(fs, orc, case):
+    over = {}
+    if case == "huge_pressure":
+        over = dict(pressure_constant=3.0e33)              # dx*kern*shared beyond 2^60, some overflow to inf
+    sim, ref, st, tick = make_pair(fs, orc, 4096, seed=21, **over)
+    p = ref.particles()
+    n = p.shape[0]
+    base = p["position"][100].copy()
+    if case == "tiny_offsets":                             # |ox|, |oy| from 2^-149 up to ~2^-20 (r2 below 2^-40 too)
+        for k, d in enumerate([1e-45, 1e-40, 1e-30, 1e-19, 3e-13, 1e-7]):
+            p["position"][101 + k] = base + np.float32(d) * np.array([1, 0 if k % 2 else 1], np.float32)
+        p["position"][100:108] -= base                     # around the origin, where such offsets are representable
+    elif case == "tiny_velocities":                        # velocity differences far below 2^-60 and denormal
+        p["velocity"][:] = 0
+        p["velocity"][::3] = (1e-30, -2e-38)
+        p["velocity"][1::3] = (3e-30, 1e-45)
+    elif case == "huge_velocities":                        # differences above 2^60 (clamped only after the force pass)
+        p["velocity"][50] = (3e30, -3e30)
+        p["velocity"][51] = (-2e25, 1e19)
+    elif case == "inf_velocity":
+        p["velocity"][60] = (np.inf, 0.0)
+        p["velocity"][61] = (-np.inf, np.nan)
+    elif case == "zero_aligned":                           # exact zeros in every numerator: lattice, equal velocities
+        q = orc.OracleSim(st, (0.0, 0.0)).particles()
+        p["position"] = q["position"]
+        p["velocity"][:] = (0.25, -0.5)
+    elif case == "near_zero_coordinates":                  # positions within 1e-20 of the origin: tiny but nonzero offsets
+        rng = np.random.default_rng(5)
+        idx = np.arange(200, 232)
+        p["position"][idx] = (rng.standard_normal((32, 2)) * 1e-22).astype(np.float32)
+    p["predicted_position"] = p["position"]
+    ref.set_particles(p); sim.upload_particles(p)
+    with np.errstate(all="ignore"):
+        run_and_compare(sim, ref, tick, 3, f"guards/{case}")
+    assert n == 4096
+
+
+def test_true_division_path_without_shared_reciprocals(fs):
+    """FS_NO_SHAREDIV=1 keeps every `/` a true IEEE division (the pre-proof body).  It is read once per
+    process, so the check runs in a child: same scene, bit-compared with the oracle there."""
+    import subprocess, sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import gpu_fluid_simulation_amd as fs
+from oracle import oracle as orc
+st, off, tick = fs.dam_break_2d(4096)
+sim = fs.FluidSimulation(st, device=0, initial_offset=off)
+assert fs.load_library().fs_constdiv_status(sim._h) & 12 == 0, "shared path should be off"
+ref = orc.OracleSim(st, off)
+for s in range(5):
+    sim.tick(tick); ref.step(tick)
+a, b = sim.download_particles(), ref.particles()
+for f in ("position", "predicted_position", "velocity", "density"):
+    assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f
+print("ok")
+'''
+    env = dict(os.environ, FS_NO_SHAREDIV="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
