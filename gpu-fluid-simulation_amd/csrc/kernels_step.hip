@@ -468,22 +468,36 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
     // plain registers: left as arrays the compiler turns the selects below into an indexed scratch load
     uint32_t la0 = la[0] << 3, la1 = la[1] << 3, la2 = la[2] << 3, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
     asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));
-    while (__any((m[0] | m[1] | m[2]) != 0u)) {
-        if ((m[0] | m[1] | m[2]) != 0u) {
-            const bool s0 = m[0] != 0u, s1 = m[1] != 0u;
-            const uint32_t cur = s0 ? m[0] : s1 ? m[1] : m[2];
-            const uint32_t t = (uint32_t)__builtin_clz(cur);
-            const uint32_t bit = 0x80000000u >> t;
-            m[0] ^= s0 ? bit : 0u;
-            m[1] ^= (!s0 && s1) ? bit : 0u;
-            m[2] ^= (!s0 && !s1) ? bit : 0u;
-            const float2 q0 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(s_flat) +
-                                                               ((s0 ? la0 : s1 ? la1 : la2) + (t << 3)));   // la* in bytes
-            const uint32_t g0 = (s0 ? lo0 : s1 ? lo1 : lo2) + t;
-            // both arrays hold 8-B elements: one 32-bit byte offset from the two SGPR bases (n < 2^29)
-            const uint32_t off = g0 << 3;
-            const float2 v0 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vel_s) + off);
-            const float2 d0 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rho2) + off);   // {density, RN(1/density)}
+    // Software-pipelined by one neighbour: the LDS read and the two gathers of neighbour k+1 are issued
+    // before the terms of neighbour k are evaluated, so a lane's own arithmetic covers their latency.
+    float2 qn = make_float2(0.0f, 0.0f), vn = qn, dn = qn;
+    bool have = false;
+    uint32_t m0 = m[0], m1 = m[1], m2 = m[2];
+#define FS_FETCH_NEXT()                                                                                              \
+    do {                                                                                                             \
+        have = (m0 | m1 | m2) != 0u;                                                                                 \
+        if (have) {                                                                                                  \
+            const bool s0 = m0 != 0u, s1 = m1 != 0u;                                                                 \
+            const uint32_t cur = s0 ? m0 : s1 ? m1 : m2;                                                             \
+            const uint32_t t = (uint32_t)__builtin_clz(cur);                                                         \
+            const uint32_t bit = 0x80000000u >> t;                                                                   \
+            m0 ^= s0 ? bit : 0u;                                                                                     \
+            m1 ^= (!s0 && s1) ? bit : 0u;                                                                            \
+            m2 ^= (!s0 && !s1) ? bit : 0u;                                                                           \
+            qn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(s_flat) +                            \
+                                                  ((s0 ? la0 : s1 ? la1 : la2) + (t << 3))); /* la* in bytes */      \
+            /* both arrays hold 8-B elements: one 32-bit byte offset from the two SGPR bases (n <= 2^28) */          \
+            const uint32_t off = ((s0 ? lo0 : s1 ? lo1 : lo2) + t) << 3;                                             \
+            vn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vel_s) + off);                       \
+            dn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rho2) + off); /* {rho, 1/rho} */     \
+        }                                                                                                            \
+    } while (0)
+    FS_FETCH_NEXT();
+    while (__any(have)) {
+        const bool cur_valid = have;
+        const float2 q0 = qn, v0 = vn, d0 = dn;
+        FS_FETCH_NEXT();
+        if (cur_valid) {
             ForceTerms T0;
             if (FAST) {
                 T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
@@ -495,6 +509,7 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
             A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
         }
     }
+#undef FS_FETCH_NEXT
 }
 
 template <bool FAST>
