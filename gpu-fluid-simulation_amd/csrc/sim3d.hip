@@ -328,23 +328,37 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& 
     }
     uint32_t la0 = la[0] << 4, la1 = la[1] << 4, la2 = la[2] << 4, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
     asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));   // keep them registers
-    while (__any((m[0] | m[1] | m[2]) != 0u)) {
-        if ((m[0] | m[1] | m[2]) != 0u) {
-            const bool s0 = m[0] != 0u, s1 = m[1] != 0u;
-            const uint32_t cur = s0 ? m[0] : s1 ? m[1] : m[2];
-            const uint32_t t = (uint32_t)__builtin_clz(cur);
-            const uint32_t bit = 0x80000000u >> t;
-            m[0] ^= s0 ? bit : 0u;
-            m[1] ^= (!s0 && s1) ? bit : 0u;
-            m[2] ^= (!s0 && !s1) ? bit : 0u;
-            const float4 q0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_flat) +
-                                                               ((s0 ? la0 : s1 ? la1 : la2) + (t << 4)));   // la* in bytes
-            const uint32_t g0 = (s0 ? lo0 : s1 ? lo1 : lo2) + t;
-            // 32-bit byte offset from the SGPR base (n <= 2^28) instead of 64-bit address arithmetic
-            const float4 v0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + (g0 << 4));
-            acc3_add(A, pair3(P, me, mv, pressure, q0, v0, A));
-        }
+    // Software-pipelined by one neighbour (as in the 2D kernel): the LDS read and the velocity gather of
+    // neighbour k+1 are issued before the terms of neighbour k are evaluated.
+    float4 qn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = qn;
+    bool have = false;
+    uint32_t m0 = m[0], m1 = m[1], m2 = m[2];
+#define FS3_FETCH_NEXT()                                                                                             \
+    do {                                                                                                             \
+        have = (m0 | m1 | m2) != 0u;                                                                                 \
+        if (have) {                                                                                                  \
+            const bool s0 = m0 != 0u, s1 = m1 != 0u;                                                                 \
+            const uint32_t cur = s0 ? m0 : s1 ? m1 : m2;                                                             \
+            const uint32_t t = (uint32_t)__builtin_clz(cur);                                                         \
+            const uint32_t bit = 0x80000000u >> t;                                                                   \
+            m0 ^= s0 ? bit : 0u;                                                                                     \
+            m1 ^= (!s0 && s1) ? bit : 0u;                                                                            \
+            m2 ^= (!s0 && !s1) ? bit : 0u;                                                                           \
+            qn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_flat) +                            \
+                                                  ((s0 ? la0 : s1 ? la1 : la2) + (t << 4))); /* la* in bytes */      \
+            /* 32-bit byte offset from the SGPR base (n <= 2^28) instead of 64-bit address arithmetic */             \
+            vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) +                             \
+                                                  (((s0 ? lo0 : s1 ? lo1 : lo2) + t) << 4));                         \
+        }                                                                                                            \
+    } while (0)
+    FS3_FETCH_NEXT();
+    while (__any(have)) {
+        const bool cur_valid = have;
+        const float4 q0 = qn, v0 = vn;
+        FS3_FETCH_NEXT();
+        if (cur_valid) acc3_add(A, pair3(P, me, mv, pressure, q0, v0, A));
     }
+#undef FS3_FETCH_NEXT
 }
 
 // The 27-cell sweep runs plane by plane (z outer).  Per plane the workgroup's three row ranges are staged
