@@ -422,7 +422,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1));
@@ -750,7 +750,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->owned.alloc(cap)); FS_TRY(s->flags.alloc(cap));

@@ -11,6 +11,8 @@ namespace fsd {
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
                     void* work, uint32_t* counter, uint32_t work_cap, bool cs_ready = false);
+// the chunked sweep of k_force reads up to 35 candidates past a row range when it scans global memory
+#define FS_PRED_SLACK 64
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
                     const uint32_t* start_ref, const u64* pairs, float* rho, float2* rho2 /* {rho, RN(1/rho)} */);
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,

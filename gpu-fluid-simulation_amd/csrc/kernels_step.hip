@@ -189,16 +189,13 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
 }
 
 // ---------------------------------------------------------- force + integrate
-// Two phases per lane so the expensive IEEE divide/sqrt body runs with dense lanes:
-//   scan  — walk the three row ranges, test `k != i && !(r2 > sqr_radius)` (compute.wgsl:195,202),
-//           append passing indices to a per-lane list in LDS (entry-major: conflict-free);
-//   heavy — pressure + viscosity terms for the listed neighbours, accumulated in list order,
-//           which is the reference visiting order, so sums keep their association.
-// A full list (FORCE_CAP) is flushed wave-uniformly and scanning resumes.
-#ifndef FORCE_CAP
-#define FORCE_CAP 16            // measured on MI355X @16M: 8: 1.12 ms, 12: 1.18, 16: 1.04, 20: 1.06, 24: 1.11, 32: 1.17
-#endif
-// neighbour-list entries per lane (u16 when staged, u32 entries = CAP/2 otherwise)
+// Two phases per lane so the expensive body (pressure + viscosity terms of one in-radius neighbour)
+// runs with dense lanes:
+//   scan  - test `k != i && !(r2 > sqr_radius)` (compute.wgsl:195,202) for the candidates of the three
+//           row ranges and record the outcome as pass bits in registers (no branches, no lists);
+//   heavy - every lane walks its set bits in the reference visiting order, so sums keep their association.
+// force_sweep_masks handles the common case (all three rows of every lane of the wave <= 32 candidates:
+// three masks, walked without idle lanes), force_sweep_chunks everything else.
 
 struct ForceAcc { float fpx, fpy, fvx, fvy; uint32_t seed; };
 struct ForceTerms { float px, py, vx, vy; };
@@ -317,109 +314,90 @@ __device__ __forceinline__ ForceTerms force_terms_shared(const StepParams& P, co
                              // few in-radius neighbours are gathered in the heavy phase (staging them too cost
                              // occupancy and measured slower: the kernel is issue-bound, not latency-bound)
 
+__device__ __forceinline__ void shift_in_not_greater(uint32_t& mask, float r2, float lim) {
+    // !(lim < r2) == !(r2 > lim), NaN included; this operand order lets `lim` stay in an SGPR
+    asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
+}
+
+// ---- chunked sweep: the general case (a row range of the wave is longer than 32, or the rows do not
+// fit the LDS tile: dense clusters).  Same machinery as the mask sweep below, one 32-candidate chunk of
+// one row at a time: wave-uniform scan of the chunk into a register mask (v_cmp + v_addc_co per
+// candidate), then every lane walks its set bits.  Rows and chunks are taken in order, so a lane still
+// visits its neighbours in the reference order; lanes idle while others finish a chunk (dense regions
+// only — the common case never comes here).  STAGED: candidates from the LDS tile, else from global
+// memory (the pred array is allocated with FS_PRED_SLACK elements of slack for the read-ahead).
 template <bool STAGED, bool FAST>
-__device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges& R, const uint32_t* blo,
-                                            uint32_t ii, const float2 me, const float2 mv, float pressure,
-                                            const float2* __restrict__ pred, const float2* __restrict__ vel_s,
-                                            const float2* __restrict__ rho2, const float2 (*s_pred)[NBF_ROW],
-                                            unsigned short* s_list16, ForceAcc& A) {
-    typedef typename std::conditional<STAGED, unsigned short, uint32_t>::type entry_t;
-    entry_t* s_list = reinterpret_cast<entry_t*>(s_list16);
-    constexpr uint32_t CAP = STAGED ? FORCE_CAP : FORCE_CAP / 2;     // same LDS bytes either way
-    const uint32_t tid = threadIdx.x;
-    uint32_t cnt = 0;
-    // plain registers (as an array the selects in the heavy phase become an indexed scratch load)
-    uint32_t blo0 = blo[0], blo1 = blo[1], blo2 = blo[2];
-    asm volatile("" : "+v"(blo0), "+v"(blo1), "+v"(blo2));
+__device__ __forceinline__ void force_sweep_chunks(const StepParams& P, const RowRanges& R, const uint32_t* blo,
+                                                   uint32_t ii, const float2 me, const float2 mv, float pressure,
+                                                   const float2* __restrict__ pred, const float2* __restrict__ vel_s,
+                                                   const float2* __restrict__ rho2, const float2* s_flat, ForceAcc& A) {
+    const float lim = P.sqr_radius;
+    // plain registers: as arrays the row selects below become dynamic indexing, which the compiler
+    // serves from scratch / promoted LDS
+    uint32_t lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2], hi0 = R.hi[0], hi1 = R.hi[1], hi2 = R.hi[2];
+    uint32_t b00 = blo[0], b01 = blo[1], b02 = blo[2];
+    asm volatile("" : "+v"(lo0), "+v"(lo1), "+v"(lo2), "+v"(hi0), "+v"(hi1), "+v"(hi2), "+v"(b00), "+v"(b01), "+v"(b02));
 #pragma unroll 1
-    for (int r = 0; r <= 3; ++r) {
-        // 4th trip only flushes; selects instead of dynamic indexing keep R/blo in registers
-        const uint32_t b0 = !STAGED ? 0u : r == 0 ? blo0 : r == 1 ? blo1 : r == 2 ? blo2 : 0u;
-        const uint32_t lo = (r == 0 ? R.lo[0] : r == 1 ? R.lo[1] : r == 2 ? R.lo[2] : 0u);
-        const uint32_t hi = (r == 0 ? R.hi[0] : r == 1 ? R.hi[1] : r == 2 ? R.hi[2] : 0u);
-        const float2* sp = s_pred[r < 3 ? r : 0] - (STAGED ? b0 : 0u);   // sp[k] is candidate k of this row
-        const float2* src = STAGED ? sp : pred;
-        const uint32_t tag = STAGED ? (((uint32_t)r << 14) - b0) : 0u;   // entry = tag + k
-        uint32_t k = lo;
-        for (;;) {
-            // scan: four candidates per trip while the list has room for all four, then singly
-            for (; k + 4u <= hi && cnt + 4u <= CAP; k += 4u) {
-                const float2 q0 = src[k], q1 = src[k + 1u], q2 = src[k + 2u], q3 = src[k + 3u];
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t lo = r == 0 ? lo0 : r == 1 ? lo1 : lo2;
+        const uint32_t hi = r == 0 ? hi0 : r == 1 ? hi1 : hi2;
+        const uint32_t b0 = r == 0 ? b00 : r == 1 ? b01 : b02;
+        const uint32_t len = hi - lo;
+#pragma unroll 1
+        for (uint32_t c0 = 0; __any(c0 < len); c0 += 32u) {              // c0 is wave-uniform
+            const uint32_t clen = c0 < len ? (len - c0 < 32u ? len - c0 : 32u) : 0u;
+            const uint32_t g = clen ? lo + c0 : 0u;                      // global index of the chunk's first candidate
+            // byte offset of the chunk's first candidate: into the LDS tile, or (32-bit, n <= 2^28) into pred
+            const uint32_t boff = (STAGED ? (clen ? (uint32_t)r * NBF_ROW + (g - b0) : 0u) : g) << 3;
+            const char* src = STAGED ? reinterpret_cast<const char*>(s_flat) : reinterpret_cast<const char*>(pred);
+#define FS_CAND(k) (*reinterpret_cast<const float2*>(src + (boff + ((k) << 3))))
+            uint32_t mask = 0, t = 0;
+            for (; __any(t < clen); t += 4u) {
+                const float2 q0 = FS_CAND(t), q1 = FS_CAND(t + 1u), q2 = FS_CAND(t + 2u), q3 = FS_CAND(t + 3u);
                 const float2 qq[4] = {q0, q1, q2, q3};
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     const float ox = qq[u].x - me.x, oyv = qq[u].y - me.y;
-                    const float r2 = ox * ox + oyv * oyv;
-                    if (k + u != ii && !(r2 > P.sqr_radius)) { s_list[cnt * FS_BLOCK + tid] = (entry_t)(tag + k + u); ++cnt; }
+                    shift_in_not_greater(mask, ox * ox + oyv * oyv, lim);
                 }
             }
-            for (; k < hi && cnt < CAP && !(k + 4u <= hi && cnt + 4u <= CAP); ++k) {
-                const float2 q = src[k];
-                const float ox = q.x - me.x, oyv = q.y - me.y;
-                const float r2 = ox * ox + oyv * oyv;
-                if (k != ii && !(r2 > P.sqr_radius)) { s_list[cnt * FS_BLOCK + tid] = (entry_t)(tag + k); ++cnt; }
-            }
-            const bool full = cnt == CAP && k < hi;
-            const bool flush = __any(full) || r > 2;
-            if (flush) {
-                if (FAST) {
-                    // heavy phase (native rcp/sqrt): two neighbours per trip, terms added in list order
-                    for (uint32_t e = 0; __any(e < cnt); e += 2u) {
-                        if (e < cnt) {
-                            const bool two = e + 1u < cnt;
-                            const uint32_t j0 = s_list[e * FS_BLOCK + tid];
-                            const uint32_t j1 = s_list[(two ? e + 1u : e) * FS_BLOCK + tid];
-                            float2 q0, q1;
-                            uint32_t g0, g1;
-                            if (STAGED) {
-                                const uint32_t r0 = j0 >> 14, o0 = j0 & 0x3FFFu, r1 = j1 >> 14, o1 = j1 & 0x3FFFu;
-                                q0 = s_pred[r0][o0]; q1 = s_pred[r1][o1];
-                                g0 = (r0 == 0 ? blo0 : r0 == 1 ? blo1 : blo2) + o0;
-                                g1 = (r1 == 0 ? blo0 : r1 == 1 ? blo1 : blo2) + o1;
-                            } else {
-                                g0 = j0; g1 = j1;
-                                q0 = pred[g0]; q1 = pred[g1];
-                            }
-                            const float2 v0 = vel_s[g0], v1 = vel_s[g1];
-                            const float d0 = rho2[g0].x, d1 = rho2[g1].x;
-                            const ForceTerms T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0, A.seed);
-                            uint32_t seed1 = A.seed;
-                            const ForceTerms T1 = force_terms<true>(P, me, mv, pressure, q1, v1, d1, seed1);
-                            A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
-                            if (two) { A.fpx += T1.px; A.fpy += T1.py; A.fvx += T1.vx; A.fvy += T1.vy; A.seed = seed1; }
-                        }
+            mask = t ? mask << (32u - t) : 0u;
+            mask &= clen ? 0xFFFFFFFFu << (32u - clen) : 0u;
+            if (r == 1 && ii - g < clen) mask &= ~(0x80000000u >> (ii - g));   // k != i
+            // walk, software-pipelined by one neighbour
+            float2 qn = make_float2(0.0f, 0.0f), vn = qn, dn = qn;
+            bool have = false;
+#define FS_FETCH_NEXT1()                                                                                             \
+    do {                                                                                                             \
+        have = mask != 0u;                                                                                           \
+        if (have) {                                                                                                  \
+            const uint32_t tt = (uint32_t)__builtin_clz(mask);                                                       \
+            mask ^= 0x80000000u >> tt;                                                                               \
+            qn = FS_CAND(tt);                                                                                        \
+            const uint32_t off = (g + tt) << 3;                                                                      \
+            vn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vel_s) + off);                       \
+            dn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rho2) + off);                        \
+        }                                                                                                            \
+    } while (0)
+            FS_FETCH_NEXT1();
+            while (__any(have)) {
+                const bool cur_valid = have;
+                const float2 q0 = qn, v0 = vn, d0 = dn;
+                FS_FETCH_NEXT1();
+                if (cur_valid) {
+                    ForceTerms T0;
+                    if (FAST) {
+                        T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
+                    } else {
+                        wave_mask good = 0;
+                        if (P.share_div) T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good);
+                        if (good != wm(true)) T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
                     }
-                } else {
-                    // heavy phase (bit-exact): one neighbour per trip — its two true divisions and seven
-                    // div_by_rcp tails are independent, so one pair already fills the pipeline and the
-                    // kernel keeps 8 waves/SIMD; the exact body runs only when a lane's operands fall
-                    // outside the proven range (wave-uniform, rare)
-                    for (uint32_t e = 0; __any(e < cnt); ++e) {
-                        if (e < cnt) {
-                            const uint32_t j0 = s_list[e * FS_BLOCK + tid];
-                            float2 q0;
-                            uint32_t g0;
-                            if (STAGED) {
-                                const uint32_t r0 = j0 >> 14, o0 = j0 & 0x3FFFu;
-                                q0 = s_pred[r0][o0];
-                                g0 = (r0 == 0 ? blo0 : r0 == 1 ? blo1 : blo2) + o0;
-                            } else {
-                                g0 = j0;
-                                q0 = pred[g0];
-                            }
-                            const float2 v0 = vel_s[g0];
-                            const float2 d0 = rho2[g0];
-                            wave_mask good = 0;
-                            ForceTerms T0;
-                            if (P.share_div) T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good);
-                            if (good != wm(true)) T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
-                            A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
-                        }
-                    }
+                    A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
                 }
-                cnt = 0;
             }
-            if (!__any(k < hi)) break;
+#undef FS_FETCH_NEXT1
+#undef FS_CAND
         }
     }
 }
@@ -432,11 +410,6 @@ __device__ __forceinline__ void force_sweep(const StepParams& P, const RowRanges
 //           own range afterwards, and the middle row clears the lane's own bit (`k != i`, :195).
 //   heavy — every lane walks its set bits, row 0, 1, 2, ascending = the reference visiting order, so
 //           the sums keep their association; all lanes stay busy until the longest list is done.
-__device__ __forceinline__ void shift_in_not_greater(uint32_t& mask, float r2, float lim) {
-    // !(lim < r2) == !(r2 > lim), NaN included; this operand order lets `lim` stay in an SGPR
-    asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
-}
-
 template <bool FAST>
 __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const RowRanges& R, const uint32_t* blo,
                                                   uint32_t ii, const float2 me, const float2 mv, float pressure,
@@ -512,15 +485,17 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
 #undef FS_FETCH_NEXT
 }
 
+// amdgpu_waves_per_eu(8, 8): with the chunked sweep inlined next to the mask sweep the allocator would take
+// 83 VGPRs (5 waves/SIMD) and the common path loses 9 %; capped at 64 it spills in the rarely taken
+// branches instead (measured: 0.77 vs 0.86 ms in the bench window, 2.67 vs 2.82 ms in the dense regime).
 template <bool FAST>
-__global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* __restrict__ pos_s,
+__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_force(StepParams P, const float2* __restrict__ pos_s,
                                                     const float2* __restrict__ vel_s,
                                                     const float2* __restrict__ pred, const float2* __restrict__ rho2,
                                                     const uint32_t* __restrict__ cs,
                                                     const uint32_t* __restrict__ start_ref,
                                                     const u64* __restrict__ pairs, const float2* __restrict__ tex,
                                                     float2* __restrict__ pos_out, float2* __restrict__ vel_out) {
-    __shared__ unsigned short s_list[FORCE_CAP * FS_BLOCK];
     __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
@@ -564,9 +539,9 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force(StepParams P, const float2* 
         if (!__any(long_row))
             force_sweep_masks<FAST>(P, R, blo, ii, me, mv, pressure, vel_s, rho2, &s_pred[0][0], A);
         else
-            force_sweep<true, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, s_pred, s_list, A);
+            force_sweep_chunks<true, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], A);
     } else {
-        force_sweep<false, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, s_pred, s_list, A);
+        force_sweep_chunks<false, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], A);
     }
     if (!live) return;
     const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
