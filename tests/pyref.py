@@ -9,6 +9,17 @@ PI = f(3.14159265359)
 EPS = f(1.19209290e-07)
 
 
+def set_float(dtype):
+    """Switch the scalar type of the whole restatement (np.float32 = the reference arithmetic; np.float64 =
+    the run the stated float tolerance is confirmed against).  Returns the previous type."""
+    global f, PI, EPS
+    prev = f
+    f = dtype
+    PI = f(3.14159265359)
+    EPS = f(1.19209290e-07)
+    return prev
+
+
 def u32sat(x):
     x = float(x)
     if not (x > 0.0):
