@@ -35,7 +35,6 @@ struct Params3 {
 };
 
 #define B3 256
-#define CAP3 16
 
 __device__ __forceinline__ float4 predict3(const Params3& P, float4 p, float4 v) {
     float4 r;
@@ -256,74 +255,51 @@ __device__ __forceinline__ Terms3 pair3(const Params3& P, float4 me, float4 mv, 
     return T;
 }
 
-// General sweep of three rows (one z-plane): scan -> per-lane list in LDS -> dense heavy phase, reading
-// the L1/L2-resident rows directly.  Used when the plane's rows do not fit the tile or a range is long.
-__device__ __forceinline__ void sweep3_list(const Params3& P, const RowRanges& R, uint32_t ii, float4 me, float4 mv,
-                                            float pressure, const float4* __restrict__ pred,
-                                            const float4* __restrict__ vel_s, uint32_t* s_list, Acc3& A) {
-    const uint32_t tid = threadIdx.x;
-    uint32_t cnt = 0;
-#pragma unroll 1
-    for (int r = 0; r <= 3; ++r) {
-        const uint32_t lo = r == 0 ? R.lo[0] : r == 1 ? R.lo[1] : r == 2 ? R.lo[2] : 0u;
-        const uint32_t hi = r == 0 ? R.hi[0] : r == 1 ? R.hi[1] : r == 2 ? R.hi[2] : 0u;
-        uint32_t k = lo;
-        for (;;) {
-            for (; k < hi && cnt < CAP3; ++k) {
-                const float4 q = pred[k];
-                const float ox = q.x - me.x, oy = q.y - me.y, oz = q.z - me.z;
-                const float r2 = ox * ox + oy * oy + oz * oz;
-                if (k != ii && !(r2 > P.h2)) { s_list[cnt * B3 + tid] = k; ++cnt; }
-            }
-            const bool full = cnt == CAP3 && k < hi;
-            if (__any(full) || r == 3) {
-                for (uint32_t e = 0; __any(e < cnt); ++e) {
-                    if (e < cnt) {
-                        const uint32_t j0 = s_list[e * B3 + tid];
-                        acc3_add(A, pair3(P, me, mv, pressure, pred[j0], vel_s[j0], A));
-                    }
-                }
-                cnt = 0;
-            }
-            if (!__any(k < hi)) break;
-        }
-    }
-}
+// (the general sweep, sweep3_chunks, follows the mask sweep below: it shares its helpers)
 
-#define TILE3_PAD 32u
+#ifndef FS3_FORCE_WAVES
+#define FS3_FORCE_WAVES 5   // measured (8 M): 4 (allocator's choice, 115 VGPRs), 5, 6 waves/SIMD -> see DESIGN.md §6
+#endif
+#define TILE3_PAD 64u
 #define TILE3_ROW (TILE3 + TILE3_PAD)
 
-// Mask sweep of one staged z-plane (see kernels_step.hip force_sweep_masks): per row a 32-bit pass
-// mask built with v_cmp + v_addc_co per candidate, then every lane walks its set bits row 0, 1, 2,
-// ascending — the oracle's visiting order.  `self_row`: the lane's own particle sits in row 1 of
-// the middle plane and is skipped (k != i).
-__device__ __forceinline__ void shift_in_not_greater3(uint32_t& mask, float r2, float lim) {
-    asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
+// Mask sweep of one staged z-plane (see kernels_step.hip force_sweep_masks).  A 3D row of three cells holds
+// ~24 candidates at rest (8 particles per cell) and passes 32 as soon as the column compresses, so the pass
+// masks are 64 bits here: v_cmp + two v_addc_co per candidate shift `!(r2 > h^2)` into a register pair,
+// then every lane walks its set bits row 0, 1, 2, ascending — the oracle's visiting order.
+// `self_plane`: the lane's own particle sits in row 1 of the middle plane and is skipped (k != i).
+__device__ __forceinline__ void shift_in_not_greater64(uint32_t& lo, uint32_t& hi, float r2, float lim) {
+    asm("v_cmp_nlt_f32 vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+        : "+v"(lo), "+v"(hi) : "v"(r2), "s"(lim) : "vcc");
 }
 
 __device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& R, const uint32_t* blo, bool self_plane,
                                              uint32_t ii, float4 me, float4 mv, float pressure,
                                              const float4* __restrict__ vel_s, const float4* s_flat, Acc3& A) {
-    uint32_t m[3], la[3];
+    typedef unsigned long long u64m;
+    u64m m[3];
+    uint32_t la[3];
     const float lim = P.h2;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const uint32_t len = R.hi[r] - R.lo[r];                           // <= 32 (caller)
+        const uint32_t len = R.hi[r] - R.lo[r];                           // <= 64 (caller)
         la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
         const float4* base = s_flat + la[r];
-        uint32_t mask = 0, t = 0;
+        uint32_t mlo = 0, mhi = 0, t = 0;
         for (; __any(t < len); t += 4u) {                                 // t is wave-uniform
             const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
             const float4 qq[4] = {q0, q1, q2, q3};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
-                shift_in_not_greater3(mask, ox * ox + oy * oy + oz * oz, lim);
+                shift_in_not_greater64(mlo, mhi, ox * ox + oy * oy + oz * oz, lim);
             }
         }
-        mask = t ? mask << (32u - t) : 0u;
-        mask &= len ? 0xFFFFFFFFu << (32u - len) : 0u;
-        if (r == 1 && self_plane && ii - R.lo[1] < len) mask &= ~(0x80000000u >> (ii - R.lo[1]));
+        // candidate t sits at bit (trips - 1 - t): left-align, keep the lane's own len candidates
+        u64m mask = ((u64m)mhi << 32) | mlo;
+        mask = t ? mask << (64u - t) : 0ull;
+        mask &= len ? ~0ull << (64u - len) : 0ull;
+        if (r == 1 && self_plane && ii - R.lo[1] < len) mask &= ~(0x8000000000000000ull >> (ii - R.lo[1]));
         m[r] = mask;
     }
     uint32_t la0 = la[0] << 4, la1 = la[1] << 4, la2 = la[2] << 4, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
@@ -332,18 +308,18 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& 
     // neighbour k+1 are issued before the terms of neighbour k are evaluated.
     float4 qn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = qn;
     bool have = false;
-    uint32_t m0 = m[0], m1 = m[1], m2 = m[2];
+    u64m m0 = m[0], m1 = m[1], m2 = m[2];
 #define FS3_FETCH_NEXT()                                                                                             \
     do {                                                                                                             \
-        have = (m0 | m1 | m2) != 0u;                                                                                 \
+        have = (m0 | m1 | m2) != 0ull;                                                                               \
         if (have) {                                                                                                  \
-            const bool s0 = m0 != 0u, s1 = m1 != 0u;                                                                 \
-            const uint32_t cur = s0 ? m0 : s1 ? m1 : m2;                                                             \
-            const uint32_t t = (uint32_t)__builtin_clz(cur);                                                         \
-            const uint32_t bit = 0x80000000u >> t;                                                                   \
-            m0 ^= s0 ? bit : 0u;                                                                                     \
-            m1 ^= (!s0 && s1) ? bit : 0u;                                                                            \
-            m2 ^= (!s0 && !s1) ? bit : 0u;                                                                           \
+            const bool s0 = m0 != 0ull, s1 = m1 != 0ull;                                                             \
+            const u64m cur = s0 ? m0 : s1 ? m1 : m2;                                                                 \
+            const uint32_t t = (uint32_t)__builtin_clzll(cur);                                                       \
+            const u64m bit = 0x8000000000000000ull >> t;                                                             \
+            m0 ^= s0 ? bit : 0ull;                                                                                   \
+            m1 ^= (!s0 && s1) ? bit : 0ull;                                                                          \
+            m2 ^= (!s0 && !s1) ? bit : 0ull;                                                                         \
             qn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_flat) +                            \
                                                   ((s0 ? la0 : s1 ? la1 : la2) + (t << 4))); /* la* in bytes */      \
             /* 32-bit byte offset from the SGPR base (n <= 2^28) instead of 64-bit address arithmetic */             \
@@ -361,15 +337,82 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& 
 #undef FS3_FETCH_NEXT
 }
 
+// General sweep of three rows (one z-plane) for waves that hold a row longer than 64 candidates, or whose
+// plane does not fit the LDS tile: the same machinery one 32-candidate chunk of one row at a time (see
+// kernels_step.hip force_sweep_chunks) — wave-uniform scan into a 32-bit mask, pipelined walk.  Rows and
+// chunks in order = the oracle's visiting order.  STAGED: candidates from the LDS tile, else from global
+// memory (pred is allocated with FS_PRED_SLACK elements of slack for the read-ahead).
+__device__ __forceinline__ void shift_in_not_greater32(uint32_t& mask, float r2, float lim) {
+    asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
+}
+template <bool STAGED>
+__device__ __forceinline__ void sweep3_chunks(const Params3& P, const RowRanges& R, const uint32_t* blo, bool self_plane,
+                                              uint32_t ii, float4 me, float4 mv, float pressure,
+                                              const float4* __restrict__ pred, const float4* __restrict__ vel_s,
+                                              const float4* s_flat, Acc3& A) {
+    const float lim = P.h2;
+    uint32_t lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2], hi0 = R.hi[0], hi1 = R.hi[1], hi2 = R.hi[2];
+    uint32_t b00 = blo[0], b01 = blo[1], b02 = blo[2];
+    asm volatile("" : "+v"(lo0), "+v"(lo1), "+v"(lo2), "+v"(hi0), "+v"(hi1), "+v"(hi2), "+v"(b00), "+v"(b01), "+v"(b02));
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t lo = r == 0 ? lo0 : r == 1 ? lo1 : lo2;
+        const uint32_t hi = r == 0 ? hi0 : r == 1 ? hi1 : hi2;
+        const uint32_t b0 = r == 0 ? b00 : r == 1 ? b01 : b02;
+        const uint32_t len = hi - lo;
+#pragma unroll 1
+        for (uint32_t c0 = 0; __any(c0 < len); c0 += 32u) {              // c0 is wave-uniform
+            const uint32_t clen = c0 < len ? (len - c0 < 32u ? len - c0 : 32u) : 0u;
+            const uint32_t g = clen ? lo + c0 : 0u;                      // global index of the chunk's first candidate
+            const uint32_t boff = (STAGED ? (clen ? (uint32_t)r * TILE3_ROW + (g - b0) : 0u) : g) << 4;
+            const char* src = STAGED ? reinterpret_cast<const char*>(s_flat) : reinterpret_cast<const char*>(pred);
+#define FS3_CAND(k) (*reinterpret_cast<const float4*>(src + (boff + ((k) << 4))))
+            uint32_t mask = 0, t = 0;
+            for (; __any(t < clen); t += 4u) {
+                const float4 q0 = FS3_CAND(t), q1 = FS3_CAND(t + 1u), q2 = FS3_CAND(t + 2u), q3 = FS3_CAND(t + 3u);
+                const float4 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
+                    shift_in_not_greater32(mask, ox * ox + oy * oy + oz * oz, lim);
+                }
+            }
+            mask = t ? mask << (32u - t) : 0u;
+            mask &= clen ? 0xFFFFFFFFu << (32u - clen) : 0u;
+            if (r == 1 && self_plane && ii - g < clen) mask &= ~(0x80000000u >> (ii - g));   // k != i
+            float4 qn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = qn;
+            bool have = false;
+#define FS3_FETCH_NEXT1()                                                                                            \
+    do {                                                                                                             \
+        have = mask != 0u;                                                                                           \
+        if (have) {                                                                                                  \
+            const uint32_t tt = (uint32_t)__builtin_clz(mask);                                                       \
+            mask ^= 0x80000000u >> tt;                                                                               \
+            qn = FS3_CAND(tt);                                                                                       \
+            vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + ((g + tt) << 4));           \
+        }                                                                                                            \
+    } while (0)
+            FS3_FETCH_NEXT1();
+            while (__any(have)) {
+                const bool cur_valid = have;
+                const float4 q0 = qn, v0 = vn;
+                FS3_FETCH_NEXT1();
+                if (cur_valid) acc3_add(A, pair3(P, me, mv, pressure, q0, v0, A));
+            }
+#undef FS3_FETCH_NEXT1
+#undef FS3_CAND
+        }
+    }
+}
+
 // The 27-cell sweep runs plane by plane (z outer).  Per plane the workgroup's three row ranges are staged
-// into LDS (as in k3_density) and swept with register pass-masks; planes whose rows do not fit the
-// tile, or that hold a range longer than 32, take the list sweep over global memory.
-__global__ __launch_bounds__(B3) void k3_force(Params3 P, const float4* __restrict__ pos_s,
+// into LDS (as in k3_density) and swept with register pass-masks (sweep3_masks); waves that hold a range
+// longer than 64, and planes whose rows do not fit the tile, take the chunked sweep.
+__global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES, FS3_FORCE_WAVES))) void k3_force(Params3 P, const float4* __restrict__ pos_s,
                                                const float4* __restrict__ vel_s, const float4* __restrict__ pred,
                                                const uint32_t* __restrict__ cs, float4* __restrict__ pos_out,
                                                float4* __restrict__ vel_out) {
-    // one buffer: the staged plane (3 x TILE3_ROW float4) or, on the general path, the neighbour list
-    __shared__ float4 s_buf[3 * TILE3_ROW > CAP3 * B3 / 4 ? 3 * TILE3_ROW : CAP3 * B3 / 4];
+    __shared__ float4 s_buf[3 * TILE3_ROW];           // the staged plane
     __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * B3 + tid;
@@ -400,17 +443,16 @@ __global__ __launch_bounds__(B3) void k3_force(Params3 P, const float4* __restri
         }
         uint32_t blo[3], bhi[3];
         const bool fit = block_tile_bounds(R, s_red, blo, bhi, TILE3);
-        const bool long_row = R.hi[0] - R.lo[0] > 32u || R.hi[1] - R.lo[1] > 32u || R.hi[2] - R.lo[2] > 32u;
-        // block-uniform choice (the two paths use s_buf differently): any long row anywhere -> list path
-        const bool masks = fit && !__syncthreads_or(long_row);
-        if (masks) {
+        const bool long_row = R.hi[0] - R.lo[0] > 64u || R.hi[1] - R.lo[1] > 64u || R.hi[2] - R.lo[2] > 64u;
+        if (fit) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
                 for (uint32_t j = tid; j < bhi[r] - blo[r]; j += B3) s_buf[r * TILE3_ROW + j] = pred[blo[r] + j];
             __syncthreads();
-            sweep3_masks(P, R, blo, plane == 1, ii, me, mv, pressure, vel_s, s_buf, A);
+            if (!__any(long_row)) sweep3_masks(P, R, blo, plane == 1, ii, me, mv, pressure, vel_s, s_buf, A);
+            else sweep3_chunks<true>(P, R, blo, plane == 1, ii, me, mv, pressure, pred, vel_s, s_buf, A);
         } else {
-            sweep3_list(P, R, ii, me, mv, pressure, pred, vel_s, reinterpret_cast<uint32_t*>(s_buf), A);
+            sweep3_chunks<false>(P, R, blo, plane == 1, ii, me, mv, pressure, pred, vel_s, s_buf, A);
         }
         __syncthreads();     // the next plane reuses s_buf / s_red
     }
@@ -618,7 +660,7 @@ fs_status fs3_create(const fs3_settings* st, int device, fs_vec3 off, fs_sim3** 
 #define T3(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { s->release(); delete s; return fail3(FS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
     T3(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t n = s->n;
-    T3(s->pos.alloc(n)); T3(s->vel.alloc(n)); T3(s->pos_s.alloc(n)); T3(s->vel_s.alloc(n)); T3(s->pred.alloc(n));
+    T3(s->pos.alloc(n)); T3(s->vel.alloc(n)); T3(s->pos_s.alloc(n)); T3(s->vel_s.alloc(n)); T3(s->pred.alloc(n + FS_PRED_SLACK));
     T3(s->key.alloc(n)); T3(s->pairs.alloc(n)); T3(s->cs.alloc((size_t)s->ncell + 1)); T3(s->counter.alloc(4));
     T3(s->dirty.alloc(fsd::sort_tile_count((uint32_t)n))); T3(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
     T3(s->aos.alloc(n));
