@@ -1,4 +1,4 @@
-"""N>1 path on CPU: pure partition logic + a world_size-2 gloo run of multi.SlabDriver /
+"""N>1 path on CPU: pure partition logic + a world_size-2/3/4 gloo runs of multi.SlabDriver /
 multi.Transport with the oracle-backed engine, compared with the single-domain oracle."""
 import os
 import subprocess
@@ -76,7 +76,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_gloo_world_slabs_match_single_domain(fs, orc, tmp_path, world):
     n, steps, more = 1024, 5, 11
     script = tmp_path / "worker.py"
