@@ -73,7 +73,7 @@ class InProcessSlabs:
             assert c["lost"] == 0 and c["overflow"] == 0 and c["far_halo"] == 0, c
 
 
-@pytest.mark.parametrize("world,n,seed", [(2, 4096, None), (3, 4096, 7), (4, 16384, 3)])
+@pytest.mark.parametrize("world,n,seed", [(2, 4096, None), (3, 4096, 7), (4, 16384, 3), (8, 65536, 5)])
 def test_slabs_match_single_gpu(fs, world, n, seed):
     from tests.slab_oracle import assert_statistics_close, match_and_compare
     st, off, tick = fs.dam_break_2d(n)
