@@ -63,6 +63,28 @@ def rebalance_boundaries(bounds, hist, max_shift, min_cols=4):
     return new
 
 
+def trim_outer_edges(bounds, hist, margin, min_cols=4):
+    """The first and last slab own everything out to the domain walls, which in a dam break is mostly empty
+    space: their local grids (and with them the cell-start table and the counting sort's scan) would be many
+    times larger than an inner slab's, and the slowest rank sets the pace.  Pull the two OUTER edges in to
+    `margin` columns beyond the occupied columns (never past the walls, never inside a neighbour).  A particle
+    that outruns the margin between two re-balancing steps is counted as `lost` by the slab engine, like any
+    other protocol violation.  margin <= 0 keeps the walls."""
+    gw = len(hist)
+    new = list(bounds)
+    occ = np.nonzero(np.asarray(hist))[0]
+    if margin <= 0 or occ.size == 0:
+        new[0], new[-1] = 0, gw
+        return new
+    new[0] = int(min(max(0, int(occ[0]) - margin), new[1] - min_cols))
+    new[-1] = int(max(min(gw, int(occ[-1]) + 1 + margin), new[-2] + min_cols))
+    return new
+
+
+def default_trim_margin():
+    return int(os.environ.get("FS_SLAB_TRIM_MARGIN", "256"))
+
+
 # ----------------------------------------------------------------------------- transport
 class Transport:
     """Exchange one byte message with each slab neighbour (rank-1 = left, rank+1 = right)."""
@@ -156,11 +178,12 @@ class HipSlabEngine:
 class SlabDriver:
     """Per-step protocol: pack -> neighbour exchange -> finish; optional re-balancing."""
 
-    def __init__(self, engine, transport, bounds, grid_w, rebalance_every=0, max_shift=2):
+    def __init__(self, engine, transport, bounds, grid_w, rebalance_every=0, max_shift=2, trim_margin=None):
         self.e, self.t = engine, transport
-        self.bounds = list(bounds)
+        self.bounds = list(bounds)                 # bounds[0] / bounds[-1] are the (possibly trimmed) outer edges
         self.grid_w = grid_w
         self.rebalance_every, self.max_shift = rebalance_every, max_shift
+        self.trim_margin = default_trim_margin() if trim_margin is None else trim_margin
         self.steps = 0
 
     def step(self, tick):
@@ -180,6 +203,7 @@ class SlabDriver:
         dist.all_reduce(th)                       # tiny (grid_w * 8 B), every K steps only
         hist = th.cpu().numpy()
         new = rebalance_boundaries(self.bounds, hist, self.max_shift)
+        new = trim_outer_edges(new, hist, self.trim_margin)     # outer edges follow the occupied columns
         if new != self.bounds:
             self.bounds = new
             self.e.set_window(new[self.t.rank], new[self.t.rank + 1])
@@ -230,7 +254,8 @@ def bench_main(args, rank, local_rank, world):
     gh = int(np.ceil(np.float32(settings.size.y) / np.float32(settings.smoothing_radius))) + 2
     bounds = partition_columns(hist, world)
     cap, recv = slab_capacities(n, world, gh)
-    max_cols = min(gw, 2 * max(bounds[k + 1] - bounds[k] for k in range(world)) + 64)
+    max_cols = min(gw, 2 * max(bounds[k + 1] - bounds[k] for k in range(world)) + 64)   # room to grow back to the walls
+    bounds = trim_outer_edges(bounds, hist, default_trim_margin())                      # outer slabs: occupied columns + margin
     msg_bytes = HEADER_BYTES + RECORD_BYTES * recv
     dev = torch.device("cuda", local_rank) if backend == "nccl" else None
     tr = Transport(rank, world, msg_bytes, device=dev)
@@ -273,7 +298,8 @@ def bench_main(args, rank, local_rank, world):
             "config": {"workload": args.workload, "particles": n, "scene": "SURVEY.md §8d dam_break_2d",
                        "sort": "counting (slab default: per-rank sorts are tolerance-parity by construction)",
                        "parallelism": f"{world} column slabs, RCCL p2p halo ({backend})",
-                       "slab_columns": [bounds[k + 1] - bounds[k] for k in range(world)],
+                       "slab_columns": [drv.bounds[k + 1] - drv.bounds[k] for k in range(world)],
+                       "outer_trim_margin": drv.trim_margin,
                        "message_bytes": msg_bytes},
             "roofline": {"bound": "hbm", "kernel": "whole step (aggregate over GPUs)", "achieved": round(agg, 1),
                          "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(agg / (HBM_PEAK_GBS * world), 4),

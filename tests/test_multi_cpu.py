@@ -23,6 +23,22 @@ def test_partition_equal_counts(fs):
         assert max(counts) <= 4096 / world + 2 * hist.max()
 
 
+def test_trim_outer_edges(fs):
+    from gpu_fluid_simulation_amd import multi
+    hist = np.zeros(100, dtype=np.int64)
+    hist[20:40] = 7
+    b = multi.partition_columns(hist, 4)
+    t = multi.trim_outer_edges(b, hist, 5)
+    assert t[0] == 15 and t[-1] == 45 and t[1:-1] == b[1:-1]
+    assert multi.trim_outer_edges(b, hist, 0) == b                       # margin 0: the walls
+    assert multi.trim_outer_edges(b, hist, 1000) == b                    # never past the walls
+    wide = multi.trim_outer_edges([0, 10, 30, 100], hist, 0)
+    assert wide == [0, 10, 30, 100]
+    squeezed = multi.trim_outer_edges([0, 21, 39, 100], hist, 0 + 1)     # never inside a neighbour (min 4 columns)
+    assert squeezed[0] <= 21 - 4 and squeezed[-1] >= 39 + 4
+    assert multi.trim_outer_edges(b, np.zeros(100, dtype=np.int64), 5) == b   # nothing to follow
+
+
 def test_rebalance_moves_towards_ideal(fs):
     from gpu_fluid_simulation_amd import multi
     hist = np.zeros(100, dtype=np.int64)

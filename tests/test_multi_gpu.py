@@ -15,9 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class InProcessSlabs:
-    def __init__(self, fs, settings, off, world, cap, recv, seed=None, vel=1.0, sort_mode=None):
+    def __init__(self, fs, settings, off, world, cap, recv, seed=None, vel=1.0, sort_mode=None, trim_margin=0):
         from gpu_fluid_simulation_amd import multi
-        self.fs, self.multi, self.world = fs, multi, world
+        self.fs, self.multi, self.world, self.trim_margin = fs, multi, world, trim_margin
         lat = fs.reference_lattice(settings, off)
         if seed is not None:
             rng = np.random.default_rng(seed)
@@ -28,7 +28,7 @@ class InProcessSlabs:
         cols = multi.global_columns(lat["position"][:, 0], settings.size.x, settings.smoothing_radius)
         self.gw = int(np.ceil(np.float32(settings.size.x) / np.float32(settings.smoothing_radius))) + 2
         hist = np.bincount(cols, minlength=self.gw)[: self.gw]
-        self.bounds = multi.partition_columns(hist, world)
+        self.bounds = multi.trim_outer_edges(multi.partition_columns(hist, world), hist, trim_margin)
         self.sims, self.bufs = [], []
         for r in range(world):
             s = fs.SlabSimulation(settings, self.bounds[r], self.bounds[r + 1], r > 0, r < world - 1, cap, recv,
@@ -55,6 +55,7 @@ class InProcessSlabs:
         for s in self.sims:
             hist += s.column_histogram(self.gw)
         new = self.multi.rebalance_boundaries(self.bounds, hist, max_shift)
+        new = self.multi.trim_outer_edges(new, hist, self.trim_margin)
         for r, s in enumerate(self.sims):
             s.set_window(new[r], new[r + 1])
         self.bounds = new
@@ -88,6 +89,32 @@ def test_slabs_match_single_gpu(fs, world, n, seed):
             slabs.assert_clean()
             match_and_compare(slabs.owned(), single.download_particles(), st.smoothing_radius)
     slabs.assert_clean()
+    assert_statistics_close(slabs.owned(), single.download_particles(), n)
+
+
+def test_trimmed_outer_edges_follow_the_fluid(fs):
+    """Outer slabs own only the occupied columns + a margin (multi.trim_outer_edges); the edges are moved out
+    again at every re-balancing step while the dam break runs across the domain: nothing is lost, parity holds."""
+    from tests.slab_oracle import assert_statistics_close, match_and_compare
+    n = 16384
+    st, off, tick = fs.dam_break_2d(n)
+    slabs = InProcessSlabs(fs, st, off, 4, cap=n + 4 * 2048, recv=2048, trim_margin=6)
+    gw = slabs.gw
+    assert slabs.bounds[-1] < gw, "the far edge must start well inside the (mostly empty) domain"
+    single = fs.FluidSimulation(st, device=0, initial_offset=off, ref_quirks=False)
+    single.upload_particles(slabs.initial)
+    first_edge = slabs.bounds[-1]
+    for s in range(1, 161):
+        slabs.step(tick)
+        single.tick(tick)
+        if s % 4 == 0:                                  # margin 6 columns: re-balance before the front can cross it
+            slabs.rebalance(2)
+        if s == 4:
+            slabs.assert_clean()
+            match_and_compare(slabs.owned(), single.download_particles(), st.smoothing_radius)
+    slabs.assert_clean()
+    assert slabs.owned().shape[0] == n
+    assert slabs.bounds[-1] > first_edge, "the front has moved, so must the edge"
     assert_statistics_close(slabs.owned(), single.download_particles(), n)
 
 

@@ -14,8 +14,9 @@ n = 1 << 24
 st, off, tick = g.dam_break_2d(n)
 gh = int(np.ceil(np.float32(st.size.y) / np.float32(st.smoothing_radius))) + 2
 cap, recv = multi.slab_capacities(n, world, gh)
-slabs = InProcessSlabs(g, st, off, world, cap=cap, recv=recv)
-print(f"world {world}: capacity {cap} recv {recv} message {slabs.sims[0].message_bytes} B, columns {np.diff(slabs.bounds).tolist()}", flush=True)
+margin = multi.default_trim_margin()
+slabs = InProcessSlabs(g, st, off, world, cap=cap, recv=recv, trim_margin=margin)
+print(f"world {world}: capacity {cap} recv {recv} message {slabs.sims[0].message_bytes} B, outer-edge margin {margin}, columns {np.diff(slabs.bounds).tolist()}", flush=True)
 t0 = time.time()
 for s in range(1, steps + 1):
     slabs.step(tick)
@@ -27,6 +28,7 @@ for s in range(1, steps + 1):
         bad = sum(c["lost"] + c["overflow"] + c["far_halo"] for c in cs)
         print(f"step {s}: live slots {live}, violations {bad}, per-rank live {[c['n_live'] for c in cs]} ({time.time()-t0:.0f}s)", flush=True)
 own = slabs.owned()
+print("final columns:", np.diff(slabs.bounds).tolist())
 print("owned particles:", own.shape[0], "of", n, "-> conserved" if own.shape[0] == n else "-> LOST")
 assert own.shape[0] == n
 slabs.assert_clean()

@@ -10,12 +10,12 @@ world = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 st, off, tick = g.dam_break_2d(n)
 hist, gw = multi.lattice_histogram(g, st, off)
 gh = int(np.ceil(np.float32(st.size.y) / np.float32(st.smoothing_radius))) + 2
-bounds = multi.partition_columns(hist, world)
+bounds = multi.trim_outer_edges(multi.partition_columns(hist, world), hist, multi.default_trim_margin())
 cap, recv = multi.slab_capacities(n, world, gh)
 lat = g.reference_lattice(st, off)
 cols = multi.global_columns(lat["position"][:, 0], st.size.x, st.smoothing_radius)
 # emulate rank `world//2` of `world` ranks WITHOUT neighbours (no exchange): pure local cost
-r = world // 2
+r = int(sys.argv[3]) if len(sys.argv) > 3 else world // 2
 sim = g.SlabSimulation(st, bounds[r], bounds[r + 1], False, False, cap, recv, max_cols=min(gw, 2 * (bounds[r + 1] - bounds[r]) + 64))
 own = lat[(cols >= bounds[r]) & (cols < bounds[r + 1])]
 sim.upload_owned(own)
