@@ -255,14 +255,16 @@ def bench_main(args, rank, local_rank, world):
     bounds = partition_columns(hist, world)
     cap, recv = slab_capacities(n, world, gh)
     max_cols = min(gw, 2 * max(bounds[k + 1] - bounds[k] for k in range(world)) + 64)   # room to grow back to the walls
-    bounds = trim_outer_edges(bounds, hist, default_trim_margin())                      # outer slabs: occupied columns + margin
+    rebalance_every = int(os.environ.get("FS_REBALANCE_EVERY", "64"))
+    # outer slabs: occupied columns + margin — only while re-balancing keeps moving the edges with the fluid
+    bounds = trim_outer_edges(bounds, hist, default_trim_margin() if rebalance_every > 0 else 0)
     msg_bytes = HEADER_BYTES + RECORD_BYTES * recv
     dev = torch.device("cuda", local_rank) if backend == "nccl" else None
     tr = Transport(rank, world, msg_bytes, device=dev)
     eng = HipSlabEngine(g, settings, bounds, rank, world, cap, recv, max_cols, local_rank, tr)
     assert eng.message_bytes == msg_bytes
     eng.sim.upload_owned(initial_owned(g, settings, off, bounds, rank))
-    drv = SlabDriver(eng, tr, bounds, gw, rebalance_every=int(os.environ.get("FS_REBALANCE_EVERY", "64")))
+    drv = SlabDriver(eng, tr, bounds, gw, rebalance_every=rebalance_every)
 
     ext = torch.cuda.ExternalStream(eng.sim.stream_ptr, device=torch.device("cuda", local_rank))
     with torch.cuda.stream(ext):
