@@ -133,6 +133,7 @@ struct fs_sim {
     DevArray<uint32_t> slab_counters;   // [0] n_live, [2] lost, [3] overflow, [4] far_halo
     DevArray<uint32_t> hist;
     bool slab_packed = false;
+    uint32_t state_lo = 0, state_hi = 0;   // the owned window the current keys / cell starts were built with
 
     // Per-pass timing: a ring of event sets recorded on the stream; drained (synchronised
     // and accumulated) only when read or when the ring is full, never per step.
@@ -262,6 +263,17 @@ fsd::StepParams make_params(const fs_sim& s) {
 }
 
 // Prove (exhaustively, on the device) that x / c == div_const_fast(x, c, RN(1/c)) for every f32 x.
+// Stored keys, cell starts and the column origin belong to the window of the LAST step (or import); a
+// window set since then (fs_slab_set_window) only takes effect at the next pack.  Anything that reads
+// the stored state back in global coordinates must use this.
+fsd::StepParams make_params_of_state(fs_sim& s) {
+    const fs_slab_config cfg = s.slab_cfg;
+    if (s.slab && s.state_hi > s.state_lo) { s.slab_cfg.own_lo = s.state_lo; s.slab_cfg.own_hi = s.state_hi; }
+    const fsd::StepParams P = make_params(s);
+    s.slab_cfg = cfg;
+    return P;
+}
+
 fs_status prove_constdiv(hipStream_t st, uint32_t* scratch_word, float c, fsd::ConstDiv* out) {
     out->c = c;
     out->y = 1.0f / c;
@@ -798,6 +810,7 @@ fs_status fs_slab_upload_owned(fs_sim* s, const fs_particle* src, size_t n) {
     const uint32_t nl = (uint32_t)n;
     FS_HIP(hipMemcpyAsync(s->slab_counters.p, &nl, sizeof nl, hipMemcpyHostToDevice, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));
+    s->state_lo = s->slab_cfg.own_lo; s->state_hi = s->slab_cfg.own_hi;
     return FS_OK;
 }
 
@@ -836,6 +849,7 @@ fs_status fs_slab_pack(fs_sim* s, const fs_tick_settings* t, void* send_left, vo
                           s->slab_cfg.has_right ? send_right : nullptr, s->slab_counters.p, s->counter.p);
     FS_HIP(hipGetLastError());
     s->slab_packed = true;
+    s->state_lo = s->slab_cfg.own_lo; s->state_hi = s->slab_cfg.own_hi;
     return FS_OK;
 }
 
@@ -887,7 +901,7 @@ fs_status fs_slab_counters_read(fs_sim* s, fs_slab_counters* out) {
 fs_status fs_slab_download(fs_sim* s, fs_particle* dst, uint8_t* owned, size_t cap, uint32_t* n_live) {
     if (!s || !s->slab || !dst || !owned || !n_live) return fail(FS_ERR_INVALID, "bad argument");
     FS_HIP(hipSetDevice(s->device));
-    const fsd::StepParams P = make_params(*s);
+    const fsd::StepParams P = make_params_of_state(*s);
     uint32_t nl = 0;
     FS_HIP(hipMemcpyAsync(&nl, s->slab_counters.p, sizeof nl, hipMemcpyDeviceToHost, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));
@@ -906,13 +920,13 @@ fs_status fs_slab_download(fs_sim* s, fs_particle* dst, uint8_t* owned, size_t c
 fs_status fs_slab_column_histogram(fs_sim* s, uint32_t* hist, size_t grid_w_global) {
     if (!s || !s->slab || !hist || grid_w_global < s->grid_w) return fail(FS_ERR_INVALID, "bad argument");
     FS_HIP(hipSetDevice(s->device));
-    const fsd::StepParams P = make_params(*s);
+    const fsd::StepParams P = make_params_of_state(*s);
     FS_HIP(hipMemsetAsync(s->hist.p, 0, s->hist.n * sizeof(uint32_t), s->stream));
     fsd::launch_slab_colhist(s->stream, P, s->cs.p, s->hist.p);
     std::vector<uint32_t> tmp(s->grid_w);
     FS_HIP(hipMemcpyAsync(tmp.data(), s->hist.p, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));
-    for (uint32_t c = s->slab_cfg.own_lo; c < s->slab_cfg.own_hi; ++c) hist[c] = tmp[c];
+    for (uint32_t c = P.own_lo; c < P.own_hi; ++c) hist[c] = tmp[c];
     return FS_OK;
 }
 

@@ -118,6 +118,29 @@ def test_trimmed_outer_edges_follow_the_fluid(fs):
     assert_statistics_close(slabs.owned(), single.download_particles(), n)
 
 
+def test_download_between_window_change_and_step_is_consistent(fs):
+    """fs_slab_set_window only takes effect at the next pack: a download in between must still translate the
+    stored (old-window) keys to the same global cell ids."""
+    n = 16384
+    st, off, tick = fs.dam_break_2d(n)
+    slabs = InProcessSlabs(fs, st, off, 3, cap=n + 4 * 2048, recv=2048, trim_margin=6)
+    for _ in range(6):
+        slabs.step(tick)
+    before = [s.download() for s in slabs.sims]
+    new = list(slabs.bounds)
+    new[0] = max(0, new[0] - 3); new[1] += 1; new[2] -= 1; new[3] += 5      # every window moves or resizes
+    for r, sim in enumerate(slabs.sims):
+        sim.set_window(new[r], new[r + 1])
+    slabs.bounds = new
+    after = [s.download() for s in slabs.sims]
+    for (ra, oa), (rb, ob) in zip(before, after):
+        assert np.array_equal(oa, ob) and np.array_equal(ra["grid"], rb["grid"])
+        assert np.array_equal(ra["position"], rb["position"])
+    slabs.step(tick)                                    # and the run goes on cleanly in the new windows
+    slabs.assert_clean()
+    assert slabs.owned().shape[0] == n
+
+
 def test_single_slab_bitonic_equals_plain_engine(fs):
     """With the reference network selected, one slab over the whole domain is bit-identical to the plain
     engine: DEAD keys sort last and never move, so the live prefix gets the same permutation."""
