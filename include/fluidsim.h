@@ -256,7 +256,8 @@ typedef struct fs_slab_counters {
 fs_status fs_slab_create(const fs_settings* global_settings, int device, const fs_slab_config* cfg, fs_sim** out);
 /* Initial owned particles (host AoS records, any order). */
 fs_status fs_slab_upload_owned(fs_sim* sim, const fs_particle* src, size_t n);
-/* Move the owned window (re-balancing); takes effect at the next fs_slab_pack. */
+/* Move the owned window (re-balancing); takes effect at the next fs_slab_pack.  Until then fs_slab_download and
+ * fs_slab_column_histogram still describe the stored state in the window it was built with. */
 fs_status fs_slab_set_window(fs_sim* sim, uint32_t own_lo, uint32_t own_hi);
 size_t fs_slab_message_bytes(const fs_sim* sim);
 /* Begin a step: predict, classify, fill the two outgoing device messages (NULL = no neighbour). */
