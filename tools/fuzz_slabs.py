@@ -18,8 +18,9 @@ for case in range(first, first + cases):
     st, off, tick = g.dam_break_2d(n)
     margin = int(rng.choice([0, 8, 24]))
     every = int(rng.choice([2, 4]))
+    sort_mode = g.FS_SORT_BITONIC if case % 3 == 0 else None        # None: the slab default (counting sort)
     slabs = InProcessSlabs(g, st, off, world, cap=n + 4 * 4096, recv=4096, seed=case, vel=float(rng.choice([0.0, 1.0, 5.0])),
-                           trim_margin=margin)
+                           trim_margin=margin, sort_mode=sort_mode)
     single = g.FluidSimulation(st, device=0, initial_offset=off, ref_quirks=False)
     single.upload_particles(slabs.initial)
     steps = int(rng.integers(20, 60))
