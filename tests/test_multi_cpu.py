@@ -114,3 +114,38 @@ def test_gloo_world_slabs_match_single_domain(fs, orc, tmp_path, world):
     for _ in range(more):
         ref.step(tick)
     assert_statistics_close(late, ref.particles(), n)                     # then statistics (chaotic scene)
+
+
+# ---- properties of the pure partition logic (hypothesis) --------------------------------------------------------
+from hypothesis import given, settings, strategies as hst
+
+
+@settings(max_examples=200, deadline=None)
+@given(hst.integers(2, 8), hst.lists(hst.integers(0, 50), min_size=40, max_size=300), hst.integers(0, 40),
+       hst.integers(1, 5))
+def test_partition_rebalance_trim_properties(world, counts, margin, max_shift):
+    from gpu_fluid_simulation_amd import multi
+    hist = np.array(counts, dtype=np.int64)
+    gw = len(hist)
+    b = multi.partition_columns(hist, world)
+    assert len(b) == world + 1 and b[0] == 0 and b[-1] == gw
+    assert all(b[k + 1] - b[k] >= 4 for k in range(world)), b          # every slab at least 4 columns wide
+    # re-balancing never moves an interior boundary by more than max_shift and keeps the minimum width
+    shifted = list(b)
+    rng = np.random.default_rng(int(hist.sum()) + world)
+    hist2 = np.roll(hist, int(rng.integers(-10, 10)))
+    nb = multi.rebalance_boundaries(shifted, hist2, max_shift)
+    assert nb[0] == b[0] and nb[-1] == b[-1]
+    assert all(nb[k + 1] - nb[k] >= 4 for k in range(world)), nb
+    assert all(abs(nb[k] - b[k]) <= max_shift + 4 for k in range(1, world))   # +4: the minimum-width repair may add to it
+    # trimming only touches the two outer edges, stays inside the walls, never cuts into a neighbour,
+    # and keeps every occupied column owned
+    t = multi.trim_outer_edges(nb, hist2, margin)
+    assert t[1:-1] == nb[1:-1]
+    assert 0 <= t[0] <= nb[1] - 4 and nb[-2] + 4 <= t[-1] <= gw
+    occ = np.nonzero(hist2)[0]
+    if margin > 0 and occ.size:
+        assert t[0] <= occ[0] and t[-1] >= occ[-1] + 1
+        assert t[0] == max(0, min(occ[0] - margin, nb[1] - 4)) or t[0] == nb[1] - 4
+    else:
+        assert t[0] == 0 and t[-1] == gw
