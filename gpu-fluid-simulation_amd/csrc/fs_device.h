@@ -182,17 +182,6 @@ __device__ __forceinline__ bool xcd_block(uint32_t nblocks, uint32_t* logical) {
 // ranges and says whether they fit an LDS tile of `tile` entries each.
 struct RowRanges { uint32_t lo[3], hi[3]; };
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
-}
-
 // Block-wide [min lo, max hi) per sweep row; returns true when all three fit the tile.
 __device__ __forceinline__ bool block_tile_bounds(const RowRanges& R, uint32_t* s_red /*[24]*/, uint32_t* blo,
                                                   uint32_t* bhi, uint32_t tile) {

@@ -305,14 +305,15 @@ __device__ __forceinline__ ForceTerms force_terms_shared(const StepParams& P, co
     return T;
 }
 
+// k_force stages the predicted positions of its three sweep rows in LDS: NBF_TILE candidates per row plus
+// NBF_PAD of slack (the mask scans read up to 32 entries from a range start, whatever the range's length).
+// Velocity and {density, 1/density} of the few in-radius neighbours are gathered in the heavy phase instead
+// (staging them too cost occupancy and measured slower).
 #ifndef NBF_TILE
 #define NBF_TILE 384
 #endif
-#define NBF_PAD 32u                      // force_sweep_masks reads up to 32 entries from a range start
-#define NBF_ROW (NBF_TILE + NBF_PAD)     // LDS row pitch of the staged candidates
-// staged candidates (predicted positions) per sweep row in k_force; vel/rho of the
-                             // few in-radius neighbours are gathered in the heavy phase (staging them too cost
-                             // occupancy and measured slower: the kernel is issue-bound, not latency-bound)
+#define NBF_PAD 32u
+#define NBF_ROW (NBF_TILE + NBF_PAD)     // LDS row pitch
 
 __device__ __forceinline__ void shift_in_not_greater(uint32_t& mask, float r2, float lim) {
     // !(lim < r2) == !(r2 > lim), NaN included; this operand order lets `lim` stay in an SGPR
