@@ -7,7 +7,14 @@ density -> force+integrate) over all particles.  State is resident in HBM before
 timed region; timing uses HIP events on the simulation's own stream (C ABI
 fs_timed_steps / fs_profile_*), bracketed by barrier + device sync, MAX over ranks.
 
-Prints ONE JSON line on rank 0 (contract fields + `roofline` + `cpu_baseline`).
+Prints ONE JSON line on rank 0 (contract fields + `roofline` + `cpu_baseline`), plus — never as
+the headline — `alt_modes` (opt-in engine modes), `alt_windows` (the same engine over later windows
+of the same scene, where the fluid is disordered / dense) and `alt_workloads` (the other
+single-GPU configs of BASELINE.json).
+
+Profiling: `rocprofv3 ... -- python3 bench.py --no-build ...` — never build inside a profiled
+process (the profiler's preload has initialised the GPU; a build would exec compilers from it).
+Build first with `python __graft_entry__.py`.
 """
 import argparse
 import json
@@ -18,8 +25,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# SURVEY.md §8d — algorithmic (compulsory SoA) bytes per particle-step, by pass.
-ALG_BYTES = {"predict_key": 28, "sort": 12, "reorder": 48 + 4, "density": 16, "force": 48}
+# SURVEY.md §8d — algorithmic (compulsory SoA) bytes per particle-step, by pass.  predict + key
+# (28 B) run inside the first sort kernel, so their bytes are the sort pass's: 28 + 12 = 40.
+ALG_BYTES = {"sort": 28 + 12, "reorder": 48 + 4, "density": 16, "force": 48}
 ALG_TOTAL = 156                      # 28 + 60 + 4 + 16 + 48
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0
@@ -31,8 +39,12 @@ WORKLOADS = {
     "dam_break_2d_64M": 1 << 26,
     "dam_break_3d_8M": 200 ** 3,
 }
-ALG_BYTES_3D = {"predict_key": 40, "sort": 12, "reorder": 72 + 4, "density": 20, "force": 68}   # 216 B
+ALG_BYTES_3D = {"predict_key": 40, "sort": 12, "reorder": 72 + 4, "density": 20, "force": 68}   # 216 B (3D keeps predict+key as its own kernel)
 ALG_TOTAL_3D = 216
+
+# which kernel carries a pass (for the committed rocprofv3 counter summaries)
+PASS_KERNEL = {"force": "k_force", "density": "k_density", "sort": "k_bitonic_local<true, true>", "reorder": "k_reorder"}
+PASS_KERNEL_3D = {"force": "k3_force", "density": "k3_density", "sort": "k_bitonic_local", "reorder": "k3_reorder"}
 
 
 def usable_cores():
@@ -54,6 +66,7 @@ def cpu_baseline(seconds_budget=15.0):
     the same port with OpenMP over particles on all cores is reported beside it."""
     import gpu_fluid_simulation_amd as g
     from oracle import oracle as O
+    O.build()                           # the checker is built by its users, not by the product build
     n = 1 << 20
     st, off, tick = g.dam_break_2d(n)
 
@@ -82,6 +95,93 @@ def cpu_baseline(seconds_budget=15.0):
                           "sample": f"same port, OpenMP over particles, {sN} steps in {eN:.1f} s"}}
 
 
+def under_profiler():
+    pre = os.environ.get("LD_PRELOAD", "")
+    return ("rocprofiler" in pre or "rocprof" in pre or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ))
+
+
+def load_product(no_build):
+    """Build (default) or only load the HIP extension.  Under a profiler, or with --no-build, nothing is ever
+    compiled: a missing or stale library is an error (exit 3), not a fallback."""
+    import __graft_entry__ as ge
+    if no_build or under_profiler():
+        if ge.product_is_stale() and not os.environ.get("FS_ALLOW_STALE"):
+            sys.stderr.write("bench.py --no-build: gpu-fluid-simulation_amd/libfluidsim_hip.so is missing or older than its "
+                             "sources; run `python __graft_entry__.py` first (FS_ALLOW_STALE=1 overrides)\n")
+            raise SystemExit(3)
+        import gpu_fluid_simulation_amd as g
+        g.load_library()
+        return g
+    ge.build_product()
+    import gpu_fluid_simulation_amd as g
+    return g
+
+
+def per_pass_table(passes, steps, n, alg_bytes):
+    out = {}
+    for name, tot in passes.items():
+        if name not in alg_bytes:       # FS_PASS_PREDICT_KEY: fused into the sort's first kernel, an empty interval
+            continue
+        t = tot / steps
+        gbs = alg_bytes[name] * n / (t * 1e-3) / 1e9 if t > 0 else 0.0
+        out[name] = {"ms": round(t, 4), "alg_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def run_window(make_sim, tick, warmup, steps, n, alg_bytes, profiled=True):
+    """`warmup` untimed steps, then `steps` timed ones on a fresh handle.  Returns (ms_per_step, per-pass table)."""
+    sim = make_sim()
+    for _ in range(warmup):
+        sim.tick(tick)
+    sim.sync()
+    table = None
+    if profiled:
+        sim.profile(True)
+        sim.profile_read(reset=True)
+    ms = sim.timed_steps(tick, steps)
+    sim.sync()
+    if profiled:
+        passes, psteps = sim.profile_read(reset=True)
+        assert psteps == steps
+        table = per_pass_table(passes, steps, n, alg_bytes)
+        sim.profile(False)
+    sim.close()
+    return ms / steps, table
+
+
+def load_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(p))
+    except (OSError, ValueError):
+        return None
+
+
+def bound_from_evidence(dom, hbm_frac_of_copy, counters, is3d):
+    """What limits the dominant kernel, from the committed rocprofv3 counter summary (profiles/counters_latest.json,
+    produced by tools/pmc_counters.py): HBM when the algorithmic rate is near the measured copy rate, else the VALU
+    issue slots when they are mostly busy, else latency (waves parked on memory / LDS)."""
+    if counters is None:
+        return "hbm" if hbm_frac_of_copy >= 0.6 else "unknown (no counter summary committed)", None
+    kern = (PASS_KERNEL_3D if is3d else PASS_KERNEL).get(dom, dom)
+    row = None
+    for k, v in counters.get("kernels", {}).items():
+        if kern in k:
+            row = dict(v, kernel=k)
+            break
+    if row is None:
+        return "hbm" if hbm_frac_of_copy >= 0.6 else "unknown (kernel not in the counter summary)", None
+    if hbm_frac_of_copy >= 0.6:
+        b = "hbm"
+    elif row.get("valu_busy_frac", 0.0) >= 0.6:
+        b = "valu"
+    elif row.get("lds_busy_frac", 0.0) >= 0.6:
+        b = "lds"
+    else:
+        b = "latency"
+    return b, row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,7 +190,9 @@ def main():
     ap.add_argument("--workload", default="dam_break_2d_16M", choices=sorted(WORKLOADS))
     ap.add_argument("--sort", default="bitonic", choices=["bitonic", "counting"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra counting-sort measurement")
+    ap.add_argument("--no-alt", action="store_true", help="skip alt_modes / alt_windows / alt_workloads")
+    ap.add_argument("--no-build", action="store_true",
+                    help="never compile: load the prebuilt library or exit 3 (use under rocprofv3)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     args = ap.parse_args()
@@ -105,9 +207,7 @@ def main():
         # torch first: its bundled HIP runtime has the same SONAME as /opt/rocm's, so the engine
         # library binds to the one already loaded (one runtime per process).
         import torch  # noqa: F401
-    import __graft_entry__ as ge
-    ge.build()
-    import gpu_fluid_simulation_amd as g
+    g = load_product(args.no_build)
 
     if world > 1:
         from gpu_fluid_simulation_amd import multi
@@ -134,42 +234,31 @@ def main():
     sim.sync()
     t_wall = (time.perf_counter() - t_wall) * 1e3
     sim.close()
-
-    # roofline: the SAME window once more on a fresh handle, now with a HIP event at every pass boundary
-    # (they serialise the kernel boundaries and cost ~1 %, which is why the headline window runs without them)
-    sim = make_sim()
-    for _ in range(args.warmup):
-        sim.tick(tick)
-    sim.sync()
-    sim.profile(True)
-    sim.profile_read(reset=True)
-    ms_profiled = sim.timed_steps(tick, args.steps)
-    sim.sync()
-    passes, psteps = sim.profile_read(reset=True)
-    assert psteps == args.steps
-    sim.profile(False)
-
     ms_per_step = ms / args.steps
     value = n / (ms_per_step * 1e-3) / 1e6            # M particle-steps/s
 
-    per_pass = {}
-    for name, tot in passes.items():
-        t = tot / args.steps
-        gbs = alg_bytes[name] * n / (t * 1e-3) / 1e9 if t > 0 else 0.0
-        per_pass[name] = {"ms": round(t, 4), "alg_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    # roofline: the SAME window once more on a fresh handle, now with a HIP event at every pass boundary
+    # (they serialise the kernel boundaries and cost ~1 %, which is why the headline window runs without them)
+    ms_profiled, per_pass = run_window(make_sim, tick, args.warmup, args.steps, n, alg_bytes)
     dom = max(per_pass, key=lambda k: per_pass[k]["ms"])
-    traffic = args.pmc_traffic
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if traffic is None and not is3d and args.workload == "dam_break_2d_16M" and os.path.exists(tpath):
-        # HBM bytes per step of the dominant pass from the committed rocprofv3 --pmc runs (separate
-        # FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction): profiles/traffic_latest.json
-        traffic = json.load(open(tpath))["bytes_per_step_by_pass"].get(dom)
+
+    traffic, traffic_src = args.pmc_traffic, "--pmc-traffic argument (separate rocprofv3 --pmc run of this command)"
+    if traffic is None:
+        traffic_src = None
+        tl = load_json("traffic_latest.json")
+        if tl and not is3d and tl.get("particles") == n:
+            # HBM bytes per step of the dominant pass from the committed rocprofv3 --pmc runs (separate
+            # FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction) — NOT measured in this run
+            traffic = tl["bytes_per_step_by_pass"].get(dom)
+            traffic_src = "profiles/traffic_latest.json (committed; " + tl.get("window", "10+10-step window") + "), not this run"
+    counters = load_json("counters_latest.json")
+    bound, crow = bound_from_evidence(dom, per_pass[dom]["alg_GBps"] / HBM_COPY_GBS, counters, is3d)
     roofline = {
-        "bound": "hbm", "kernel": dom,
+        "bound": bound, "kernel": dom,
         "achieved": per_pass[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "profiled_ms_per_step": round(ms_profiled / args.steps, 4),
+        "profiled_ms_per_step": round(ms_profiled, 4),
         "frac": per_pass[dom]["frac"],
-        "traffic": traffic,
+        "traffic": traffic, "traffic_source": traffic_src,
         "alg_bytes_per_particle": alg_bytes[dom],
         "step": {"alg_bytes_per_particle": alg_total,
                  "achieved": round(alg_total * n / (ms_per_step * 1e-3) / 1e9, 1),
@@ -177,25 +266,28 @@ def main():
                  "frac_of_measured_copy": round(alg_total * n / (ms_per_step * 1e-3) / 1e9 / HBM_COPY_GBS, 4)},
         "passes": per_pass,
     }
+    if crow is not None:
+        # second fraction: how full the VALU issue slots of the dominant kernel are (SQ_ACTIVE_INST_VALU x 4 /
+        # (SIMDs x kernel cycles)), from the committed counter summary named in `source`
+        roofline["valu_issue"] = {"frac": crow.get("valu_busy_frac"), "insts_per_wave": crow.get("valu_insts_per_wave"),
+                                  "waves_per_simd": crow.get("waves_per_simd"), "lds_busy_frac": crow.get("lds_busy_frac"),
+                                  "wait_frac": crow.get("wait_frac"), "kernel": crow.get("kernel"),
+                                  "source": counters.get("source")}
     out = {
         "metric": "M particle-steps/s", "value": round(value, 2), "unit": "M particle-steps/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "particles": n, "scene": "SURVEY.md §8d " + ("dam_break_3d (no reference counterpart)" if is3d else "dam_break_2d"),
-                   "sort": args.sort, "ref_quirks": not is3d, "parallelism": "1 GPU"},
+                   "sort": args.sort, "ref_quirks": not is3d, "parallelism": "1 GPU",
+                   "window": f"steps {args.warmup}..{args.warmup + args.steps} from the lattice (see alt_windows for later regimes)"},
         "host_wall_ms_per_step": round(t_wall / args.steps, 4),
         "roofline": roofline,
     }
-    sim.close()
     if not is3d and args.sort == "bitonic" and not args.no_alt:
         # extras (NOT the headline): the same scene and protocol in the engine's opt-in modes
         def alt_run(**kw):
-            a = g.FluidSimulation(st, device=local_rank, initial_offset=off, **kw)
-            for _ in range(args.warmup):
-                a.tick(tick)
-            a.sync()
-            t = a.timed_steps(tick, args.steps) / args.steps
-            a.close()
+            mk = lambda: g.FluidSimulation(st, device=local_rank, initial_offset=off, **kw)
+            t, _ = run_window(mk, tick, args.warmup, args.steps, n, alg_bytes, profiled=False)
             return {"value": round(n / (t * 1e-3) / 1e6, 2), "unit": "M particle-steps/s", "ms_per_step": round(t, 4)}
         out["alt_modes"] = {
             "counting_sort": dict(alt_run(sort_mode=g.FS_SORT_COUNTING),
@@ -206,6 +298,35 @@ def main():
                                        "contract for the reference shaders); not bit-exact vs the IEEE oracle"),
             "counting_sort+wgsl_ulp_math": alt_run(sort_mode=g.FS_SORT_COUNTING, math_mode=g.FS_MATH_WGSL_ULP),
         }
+        # the same strict engine over later windows of the same scene: the block stays a near lattice for the
+        # first ~25 steps; by step 100 it is disordered, from step ~150 the bottom of the column is dense
+        aw = {}
+        for w0, w1 in ((10, 110), (150, 250)):
+            t, tab = run_window(make_sim, tick, w0, w1 - w0, n, alg_bytes)
+            aw[f"steps_{w0}_{w1}"] = {"value": round(n / (t * 1e-3) / 1e6, 2), "ms_per_step": round(t, 4),
+                                      "passes_ms": {k: v["ms"] for k, v in tab.items()},
+                                      "step_frac_of_hbm_peak": round(alg_total * n / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        out["alt_windows"] = dict(aw, note="per-pass events on (costs ~1 %); value in M particle-steps/s")
+        # the other single-GPU configs of BASELINE.json, 10 + 100 steps each
+        wl = {}
+        for name in ("dam_break_2d_1M", "dam_break_2d_64M", "dam_break_3d_8M"):
+            if name == args.workload:
+                continue
+            try:
+                m = WORKLOADS[name]
+                if name.startswith("dam_break_3d"):
+                    s3, o3, t3 = g.dam_break_3d(m)
+                    mk, tk, ab, at = (lambda: g.FluidSimulation3D(s3, device=local_rank, initial_offset=o3)), t3, ALG_BYTES_3D, ALG_TOTAL_3D
+                else:
+                    s2, o2, t2 = g.dam_break_2d(m)
+                    mk, tk, ab, at = (lambda: g.FluidSimulation(s2, device=local_rank, initial_offset=o2)), t2, ALG_BYTES, ALG_TOTAL
+                t, tab = run_window(mk, tk, 10, 100, m, ab)
+                wl[name] = {"value": round(m / (t * 1e-3) / 1e6, 2), "ms_per_step": round(t, 4), "particles": m,
+                            "passes_ms": {k: v["ms"] for k, v in tab.items()},
+                            "step_frac_of_hbm_peak": round(at * m / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            except Exception as e:      # an extra must never take the headline down with it
+                wl[name] = {"error": str(e)}
+        out["alt_workloads"] = dict(wl, note="10 warm-up + 100 timed steps each, strict mode, one GPU; 3D has no reference counterpart")
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)

@@ -42,6 +42,12 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def is_stale():
+    """True when the library is missing or older than any source/header (what build() would act on)."""
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    return _stale(OUT, deps)
+
+
 def build(force=False, verbose=True, out=None, extra_flags=()):
     """Compile and link.  `out`/`extra_flags` build an experimental variant next to the default library."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -16,7 +16,7 @@ def pytest_configure(config):
 def fs():
     """The product package (ctypes host mirror over libfluidsim_hip.so)."""
     import __graft_entry__ as ge
-    ge.build()
+    ge.build_product()      # the product build does not depend on the checker (orc fixture below)
     import gpu_fluid_simulation_amd as g
     return g
 
