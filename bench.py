@@ -173,7 +173,7 @@ def bound_from_evidence(dom, hbm_frac_of_copy, counters, is3d):
         return "hbm" if hbm_frac_of_copy >= 0.6 else "unknown (kernel not in the counter summary)", None
     if hbm_frac_of_copy >= 0.6:
         b = "hbm"
-    elif row.get("valu_busy_frac", 0.0) >= 0.6:
+    elif row.get("valu_issue_frac", 0.0) >= 0.6:
         b = "valu"
     elif row.get("lds_busy_frac", 0.0) >= 0.6:
         b = "lds"
@@ -267,9 +267,9 @@ def main():
         "passes": per_pass,
     }
     if crow is not None:
-        # second fraction: how full the VALU issue slots of the dominant kernel are (SQ_ACTIVE_INST_VALU x 4 /
-        # (SIMDs x kernel cycles)), from the committed counter summary named in `source`
-        roofline["valu_issue"] = {"frac": crow.get("valu_busy_frac"), "insts_per_wave": crow.get("valu_insts_per_wave"),
+        # second fraction: share of the VALU issue slots the dominant kernel uses (SQ_INSTS_VALU priced with the
+        # measured issue table, / (1024 SIMDs x kernel cycles)), from the committed counter summary named in `source`
+        roofline["valu_issue"] = {"frac": crow.get("valu_issue_frac"), "insts_per_wave": crow.get("valu_insts_per_wave"),
                                   "waves_per_simd": crow.get("waves_per_simd"), "lds_busy_frac": crow.get("lds_busy_frac"),
                                   "wait_frac": crow.get("wait_frac"), "kernel": crow.get("kernel"),
                                   "source": counters.get("source")}

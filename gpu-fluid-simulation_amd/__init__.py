@@ -391,6 +391,11 @@ class SlabSimulation:
         _check(self._lib, self._lib.fs_slab_column_histogram(self._h, h.ctypes.data_as(C.c_void_p), h.shape[0]))
         return h
 
+    def max_speed(self):
+        v = C.c_float()
+        _check(self._lib, self._lib.fs_slab_max_speed(self._h, C.byref(v)))
+        return float(v.value)
+
     def profile(self, enable=True):
         _check(self._lib, self._lib.fs_profile_enable(self._h, 1 if enable else 0))
 

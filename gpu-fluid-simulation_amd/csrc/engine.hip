@@ -133,6 +133,7 @@ struct fs_sim {
     DevArray<uint32_t> slab_counters;   // [0] n_live, [2] lost, [3] overflow, [4] far_halo
     DevArray<uint32_t> hist;
     bool slab_packed = false;
+    bool slab_prof = false;                // profiling state latched by fs_slab_pack for the matching fs_slab_step
     uint32_t state_lo = 0, state_hi = 0;   // the owned window the current keys / cell starts were built with
 
     // Per-pass timing: a ring of event sets recorded on the stream; drained (synchronised
@@ -676,6 +677,7 @@ fs_status fs_profile_read(fs_sim* s, double ms[FS_PASS_COUNT], uint64_t* steps, 
 
 fs_status fs_timed_steps(fs_sim* s, const fs_tick_settings* t, uint32_t steps, double* ms_total) {
     if (!s || !t || !ms_total) return fail(FS_ERR_INVALID, "null argument");
+    if (s->slab) return fail(FS_ERR_INVALID, "slab handle: use fs_slab_pack / fs_slab_step");
     FS_HIP(hipSetDevice(s->device));
     FS_HIP(hipEventRecord(s->t0, s->stream));
     for (uint32_t k = 0; k < steps; ++k) {
@@ -837,7 +839,8 @@ fs_status fs_slab_pack(fs_sim* s, const fs_tick_settings* t, void* send_left, vo
     s->tick += 1;
     host_uniform(s->settings, *t, s->tick, &s->uniform);
     const fsd::StepParams P = make_params(*s);
-    if (s->profile) {
+    s->slab_prof = s->profile;             // a toggle between pack and step must not leave ev[0] unrecorded
+    if (s->slab_prof) {
         fs_status r = ensure_events(s);
         if (r != FS_OK) return r;
         if (s->prof_pending == fs_sim::PROF_RING) { r = drain_profile(s); if (r != FS_OK) return r; }
@@ -861,7 +864,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     FS_HIP(hipSetDevice(s->device));
     const fsd::StepParams P = make_params(*s);
     hipStream_t st = s->stream;
-    hipEvent_t* ev = s->profile ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
+    hipEvent_t* ev = s->slab_prof ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
     fsd::launch_slab_unpack(st, P, s->slab_main, s->slab_cfg.recv_capacity, s->slab_cfg.has_left ? recv_left : nullptr,
                             s->slab_cfg.has_right ? recv_right : nullptr, s->pos.p, s->vel.p, s->pairs.p,
                             s->slab_counters.p);
@@ -895,6 +898,19 @@ fs_status fs_slab_counters_read(fs_sim* s, fs_slab_counters* out) {
     FS_HIP(hipMemcpyAsync(c, s->slab_counters.p, sizeof c, hipMemcpyDeviceToHost, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));
     out->n_live = c[0]; out->lost = c[2]; out->overflow = c[3]; out->far_halo = c[4];
+    return FS_OK;
+}
+
+fs_status fs_slab_max_speed(fs_sim* s, float* out) {
+    if (!s || !s->slab || !out) return fail(FS_ERR_INVALID, "bad argument");
+    if (s->slab_packed) return fail(FS_ERR_INVALID, "fs_slab_max_speed between pack and step");
+    FS_HIP(hipSetDevice(s->device));
+    uint32_t bits = 0;
+    FS_HIP(hipMemsetAsync(s->slab_counters.p + 5, 0, sizeof(uint32_t), s->stream));
+    fsd::launch_slab_maxspeed(s->stream, s->slab_counters.p, s->vel.p, s->owned.p, s->slab_counters.p + 5);
+    FS_HIP(hipMemcpyAsync(&bits, s->slab_counters.p + 5, sizeof bits, hipMemcpyDeviceToHost, s->stream));
+    FS_HIP(hipStreamSynchronize(s->stream));
+    std::memcpy(out, &bits, sizeof bits);
     return FS_OK;
 }
 

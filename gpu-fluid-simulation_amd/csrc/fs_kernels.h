@@ -52,6 +52,8 @@ void launch_slab_export(hipStream_t st, const StepParams& P, uint32_t cap, const
 void launch_slab_import(hipStream_t st, const StepParams& P, uint32_t n, uint32_t cap, const void* in, float2* pos,
                         float2* pred, float2* vel, float* rho, uint32_t* key, unsigned char* owned);
 void launch_slab_colhist(hipStream_t st, const StepParams& P, const uint32_t* cs, uint32_t* hist_global);
+void launch_slab_maxspeed(hipStream_t st, const uint32_t* n_live, const float2* vel, const unsigned char* owned,
+                          uint32_t* out_bits);
 size_t slab_message_bytes(uint32_t R);
 
 // Bitonic network of sort.wgsl:27-51 / simulation.rs:323-347 on (key<<32 | index) pairs.

@@ -59,6 +59,11 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_classify(StepParams P, uint32
         }
         pairs[i] = ((u64)key << 32) | (u64)i;
         flags[i] = f;
+    } else if (i < n_prev && owned[i]) {
+        // Slot capacity exceeded: the last step left more live records than main slots, and this owned
+        // particle sits where the incoming messages will be unpacked.  It cannot be carried over —
+        // count it (fs_slab_counters.overflow must stay 0; the driver raises on it).
+        atomicAdd(&counters[3], 1u);
     }
     const unsigned long long mL = __ballot(f & 1), mR = __ballot(f & 2);
     const uint32_t w = threadIdx.x >> 6;
@@ -285,16 +290,41 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_colhist(StepParams P, const u
     hist_global[cg] = sum;
 }
 
+// Largest |velocity| among the owned live particles, as f32 bits (non-negative floats order like their bits):
+// sizes the outer-edge margin between two re-balancing steps (multi.py).
+__global__ __launch_bounds__(SL_BLOCK) void k_slab_maxspeed(const uint32_t* __restrict__ n_live,
+                                                            const float2* __restrict__ vel,
+                                                            const unsigned char* __restrict__ owned,
+                                                            uint32_t* __restrict__ out_bits) {
+    const uint32_t n = *n_live;
+    float m = 0.0f;
+    for (uint32_t i = blockIdx.x * SL_BLOCK + threadIdx.x; i < n; i += gridDim.x * SL_BLOCK) {
+        if (!owned[i]) continue;
+        const float2 v = vel[i];
+        const float sp = sqrt_rn(v.x * v.x + v.y * v.y);
+        if (sp > m) m = sp;                                  // NaN never wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63u) == 0 && m > 0.0f) atomicMax(out_bits, __float_as_uint(m));
+}
+
 // ------------------------------------------------------------------ launchers
 static inline uint32_t nb(uint32_t n) { return (n + SL_BLOCK - 1) / SL_BLOCK; }
+
+void launch_slab_maxspeed(hipStream_t st, const uint32_t* n_live, const float2* vel, const unsigned char* owned,
+                          uint32_t* out_bits) {
+    hipLaunchKernelGGL(k_slab_maxspeed, dim3(1024), dim3(SL_BLOCK), 0, st, n_live, vel, owned, out_bits);
+}
 
 void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, int has_left,
                       int has_right, const float2* pos, const float2* vel, const unsigned char* owned, u64* pairs,
                       unsigned char* flags, void* blockcnt, void* blockoff, void* msg_left, void* msg_right,
                       uint32_t* counters, uint32_t* gap_counter) {
     const uint32_t blocks = nb(main_slots);
-    hipLaunchKernelGGL(k_slab_classify, dim3(blocks), dim3(SL_BLOCK), 0, st, P, main_slots, has_left, has_right, pos,
-                       vel, owned, pairs, flags, (uint2*)blockcnt, counters, gap_counter);
+    // classify covers ALL slots (P.n = capacity): slots past `main_slots` only check for stranded owned particles
+    hipLaunchKernelGGL(k_slab_classify, dim3(nb(P.n > main_slots ? P.n : main_slots)), dim3(SL_BLOCK), 0, st, P, main_slots,
+                       has_left, has_right, pos, vel, owned, pairs, flags, (uint2*)blockcnt, counters, gap_counter);
     SlabHeader* hl = (SlabHeader*)msg_left;
     SlabHeader* hr = (SlabHeader*)msg_right;
     hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SCAN_THREADS), 0, st, (const uint2*)blockcnt, blocks, (uint2*)blockoff,

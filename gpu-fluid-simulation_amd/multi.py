@@ -82,7 +82,26 @@ def trim_outer_edges(bounds, hist, margin, min_cols=4):
 
 
 def default_trim_margin():
+    """Floor of the outer-edge margin in columns (FS_SLAB_TRIM_MARGIN); the margin actually used is
+    max(this, travel_margin(...)) so that it is tied to how far the fluid can move before the next re-trim."""
     return int(os.environ.get("FS_SLAB_TRIM_MARGIN", "256"))
+
+
+SPEED_CLAMP = 500.0          # compute.wgsl:118-122: |v| <= 500 after every step
+
+
+def travel_margin(vmax, accel, dt, h, steps, safety=1.5):
+    """Columns a particle can cross in `steps` steps: it moves at most (safety * vmax + accel * dt * k) * dt in
+    step k (vmax = largest speed now, all ranks; accel = |gravity|, the one body force; `safety` covers pressure
+    pushes), never faster than the engine's speed clamp.  +2: the slab's own 2-column halo tolerance."""
+    v_end = min(SPEED_CLAMP, safety * float(vmax) + float(accel) * float(dt) * steps)
+    v_mean = min(SPEED_CLAMP, 0.5 * (safety * float(vmax) + v_end))
+    return int(np.ceil(steps * v_mean * float(dt) / float(h))) + 2
+
+
+class SlabProtocolError(RuntimeError):
+    """A device counter (lost / overflow / far_halo) is non-zero: particles were dropped or a message / the slot
+    array overflowed.  The run is no longer a valid simulation of the scene."""
 
 
 # ----------------------------------------------------------------------------- transport
@@ -171,52 +190,112 @@ class HipSlabEngine:
     def counters(self):
         return self.sim.counters()
 
+    def max_speed(self):
+        return self.sim.max_speed()
+
     def sync(self):
         self.sim.sync()
 
 
 class SlabDriver:
-    """Per-step protocol: pack -> neighbour exchange -> finish; optional re-balancing."""
+    """Per-step protocol: pack -> neighbour exchange -> finish; optional re-balancing.
 
-    def __init__(self, engine, transport, bounds, grid_w, rebalance_every=0, max_shift=2, trim_margin=None):
+    Every re-balancing step (already a host synchronisation) also (1) reads the device violation counters of
+    every rank and raises SlabProtocolError if any is non-zero — a long run can no longer delete particles
+    silently; (2) sizes the outer-edge margin from the largest particle speed of all ranks and the number of
+    steps until the next re-trim (`travel_margin`), never below `trim_margin`; (3) shortens the interval to the
+    next re-balancing step while the partition is badly unbalanced (boundaries move at most `max_shift` columns
+    per step, so a rank could otherwise outgrow its slot capacity between two of them)."""
+
+    def __init__(self, engine, transport, bounds, grid_w, rebalance_every=0, max_shift=2, trim_margin=None,
+                 capacity_main=None, check_counters=True, max_cols=None):
         self.e, self.t = engine, transport
         self.bounds = list(bounds)                 # bounds[0] / bounds[-1] are the (possibly trimmed) outer edges
         self.grid_w = grid_w
         self.rebalance_every, self.max_shift = rebalance_every, max_shift
         self.trim_margin = default_trim_margin() if trim_margin is None else trim_margin
+        self.capacity_main = capacity_main         # main slots per rank (None: no capacity-driven interval)
+        self.check_counters = check_counters
+        self.max_cols = max_cols                   # widest window the engine was created for (None: the whole grid)
         self.steps = 0
+        self.next_rebalance = rebalance_every
+        self.last_margin = self.trim_margin
+        self.tick = None
 
     def step(self, tick):
+        self.tick = tick
         self.e.pack(tick)
         self.t.exchange()
         self.e.finish()
         self.steps += 1
-        if self.rebalance_every and self.steps % self.rebalance_every == 0:
+        if self.rebalance_every and self.steps >= self.next_rebalance:
             self.rebalance()
 
-    def rebalance(self):
+    def _allreduce(self, arr, op):
         torch, dist = self.t.torch, self.t.dist
-        hist = self.e.column_histogram(self.grid_w).astype(np.int64)
-        th = torch.from_numpy(hist)
+        th = torch.from_numpy(arr)
         if self.t.device is not None:
             th = th.to(self.t.device)
-        dist.all_reduce(th)                       # tiny (grid_w * 8 B), every K steps only
-        hist = th.cpu().numpy()
+        dist.all_reduce(th, op=op)
+        return th.cpu().numpy()
+
+    def rebalance(self):
+        dist = self.t.dist
+        hist = self.e.column_histogram(self.grid_w).astype(np.int64)
+        hist = self._allreduce(hist, dist.ReduceOp.SUM)          # tiny (grid_w * 8 B), every K steps only
+        # violations + largest speed of any rank, one more tiny all-reduce (MAX)
+        c = self.e.counters() if (self.check_counters and hasattr(self.e, "counters")) else {}
+        vmax = float(self.e.max_speed()) if hasattr(self.e, "max_speed") else SPEED_CLAMP
+        stats = np.array([c.get("lost", 0), c.get("overflow", 0), c.get("far_halo", 0), vmax], dtype=np.float64)
+        stats = self._allreduce(stats, dist.ReduceOp.MAX)
+        if stats[:3].any():
+            raise SlabProtocolError(f"slab protocol violated at step {self.steps}: max over ranks of lost/overflow/far_halo = "
+                                    f"{int(stats[0])}/{int(stats[1])}/{int(stats[2])} (this rank: {c})")
+        world = len(self.bounds) - 1
+        owned = np.array([hist[self.bounds[k]:self.bounds[k + 1]].sum() for k in range(world)], dtype=np.float64)
+        interval = self.rebalance_every
+        if owned.sum() > 0:
+            worst = owned.max()
+            limit = 0.9 * self.capacity_main if self.capacity_main else 1.15 * owned.mean()
+            if worst > limit:                     # catching up: boundaries move <= max_shift columns per re-balancing step
+                interval = max(1, self.rebalance_every // 8)
+            elif worst > 1.10 * owned.mean():
+                interval = max(1, self.rebalance_every // 2)
+        self.next_rebalance = self.steps + interval
         new = rebalance_boundaries(self.bounds, hist, self.max_shift)
-        new = trim_outer_edges(new, hist, self.trim_margin)     # outer edges follow the occupied columns
+        margin = self.trim_margin
+        if margin > 0 and self.tick is not None:
+            g = self.tick.gravity
+            accel = float(np.hypot(g.x, g.y))
+            margin = max(margin, travel_margin(stats[3], accel, self.tick.delta, self._h(), interval))
+        self.last_margin = margin
+        new = trim_outer_edges(new, hist, margin)               # outer edges follow the occupied columns
+        if self.max_cols:                                       # never wider than the engine's tables
+            new[0] = max(new[0], new[1] - self.max_cols)
+            new[-1] = min(new[-1], new[-2] + self.max_cols)
         if new != self.bounds:
             self.bounds = new
             self.e.set_window(new[self.t.rank], new[self.t.rank + 1])
+
+    def _h(self):
+        st = getattr(self.e, "settings", None) or getattr(getattr(self.e, "sim", None), "settings", None)
+        return float(st.smoothing_radius) if st is not None else 1.0
 
 
 # ----------------------------------------------------------------------------- setup helpers
 def slab_capacities(n_total, world, grid_h, headroom=1.25):
     """(capacity, recv_capacity).  A message carries 2 ghost columns + migrants: ~2 * grid_h * 4 records at
     lattice density; 3 * grid_h * 8 leaves ~3x headroom (the device counters flag an overflow).  Smaller
-    messages matter: they are sent at full size every step (no host sync to learn the real count)."""
+    messages matter: they are sent at full size every step (no host sync to learn the real count).
+    Main slots hold the worst-case owned share (mean * headroom — SlabDriver re-balances more often once a rank
+    passes 90 % of it) plus the 4 ghost columns that are live after a step (2 per side, 10 particles per cell)."""
     recv = max(4096, 3 * grid_h * 8)
     main = int(n_total / world * headroom) + 4 * grid_h * 10 + 4096
     return main + 2 * recv, recv
+
+
+def main_slots(capacity, recv_capacity):
+    return capacity - 2 * recv_capacity
 
 
 def initial_owned(g, settings, offset, bounds, rank):
@@ -254,7 +333,7 @@ def bench_main(args, rank, local_rank, world):
     gh = int(np.ceil(np.float32(settings.size.y) / np.float32(settings.smoothing_radius))) + 2
     bounds = partition_columns(hist, world)
     cap, recv = slab_capacities(n, world, gh)
-    max_cols = min(gw, 2 * max(bounds[k + 1] - bounds[k] for k in range(world)) + 64)   # room to grow back to the walls
+    max_cols = gw      # tables for the whole grid (42 MB each at 16M): the outer-edge margin follows the fluid's speed
     rebalance_every = int(os.environ.get("FS_REBALANCE_EVERY", "64"))
     # outer slabs: occupied columns + margin — only while re-balancing keeps moving the edges with the fluid
     bounds = trim_outer_edges(bounds, hist, default_trim_margin() if rebalance_every > 0 else 0)
@@ -264,7 +343,7 @@ def bench_main(args, rank, local_rank, world):
     eng = HipSlabEngine(g, settings, bounds, rank, world, cap, recv, max_cols, local_rank, tr)
     assert eng.message_bytes == msg_bytes
     eng.sim.upload_owned(initial_owned(g, settings, off, bounds, rank))
-    drv = SlabDriver(eng, tr, bounds, gw, rebalance_every=rebalance_every)
+    drv = SlabDriver(eng, tr, bounds, gw, rebalance_every=rebalance_every, capacity_main=main_slots(cap, recv), max_cols=max_cols)
 
     ext = torch.cuda.ExternalStream(eng.sim.stream_ptr, device=torch.device("cuda", local_rank))
     with torch.cuda.stream(ext):

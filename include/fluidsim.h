@@ -249,7 +249,8 @@ typedef struct fs_slab_config {
 typedef struct fs_slab_counters {
     uint32_t n_live;        /* live slots after the last step (owned + ghosts) */
     uint32_t lost;          /* particles that left slab + halo in one step (must stay 0) */
-    uint32_t overflow;      /* message or slot capacity exceeded (must stay 0) */
+    uint32_t overflow;      /* message capacity exceeded, or owned particles stranded past the main slots
+                               (n_live > capacity - 2*recv_capacity at the next pack); must stay 0 */
     uint32_t far_halo;      /* migrants that landed in the receiver's far halo zone (must stay 0) */
 } fs_slab_counters;
 
@@ -267,6 +268,9 @@ fs_status fs_slab_step(fs_sim* sim, const void* recv_left, const void* recv_righ
 fs_status fs_slab_counters_read(fs_sim* sim, fs_slab_counters* out);   /* blocking */
 /* Live records (global cell keys) and their owned flags; blocking.  Returns n_live. */
 fs_status fs_slab_download(fs_sim* sim, fs_particle* dst, uint8_t* owned, size_t cap, uint32_t* n_live);
+/* Largest |velocity| among the owned particles (sizes the outer-edge margin between two re-balancing
+ * steps: a wall-side slab must contain everything that can move before the next one); blocking. */
+fs_status fs_slab_max_speed(fs_sim* sim, float* out);
 /* Per-global-column particle counts of the owned columns (others untouched); blocking. */
 fs_status fs_slab_column_histogram(fs_sim* sim, uint32_t* hist, size_t grid_w_global);
 

@@ -80,8 +80,10 @@ tr = multi.Transport(rank, world, multi.HEADER_BYTES + multi.RECORD_BYTES * 4096
 eng = OracleSlabEngine(O, st, bounds, rank, world, tr)
 eng.upload_owned(multi.initial_owned(g, st, off, bounds, rank))
 drv = multi.SlabDriver(eng, tr, bounds, gw, rebalance_every=4, max_shift=1)
-for _ in range(steps):
+for k in range(steps):
     drv.step(tick)
+    if k == 1:
+        np.save(os.path.join(sys.argv[4], f"early_{rank}.npy"), eng.owned_particles())
 own = eng.owned_particles()
 np.save(os.path.join(sys.argv[4], f"owned_{rank}.npy"), own)
 for _ in range(int(sys.argv[5])):
@@ -106,14 +108,98 @@ def test_gloo_world_slabs_match_single_domain(fs, orc, tmp_path, world):
     got = np.concatenate([np.load(tmp_path / f"owned_{r}.npy") for r in range(world)])
     st, off, tick = fs.dam_break_2d(n)
     ref = orc.OracleSim(st, off, ref_quirks=False)
-    for _ in range(steps):
-        ref.step(tick)
     from tests.slab_oracle import assert_statistics_close, match_and_compare
-    match_and_compare(got, ref.particles(), st.smoothing_radius)          # elementwise while ULP noise is small
+    for k in range(steps):
+        ref.step(tick)
+        if k == 1:    # step 2: cell keys of matched particles are IDENTICAL (north_star: cell indices bit-exact)
+            early = np.concatenate([np.load(tmp_path / f"early_{r}.npy") for r in range(world)])
+            match_and_compare(early, ref.particles(), st.smoothing_radius, max_key_flips=0.0)
+    # step 5: elementwise while ULP noise is small.  Whole lattice columns of this scene sit EXACTLY on a cell
+    # boundary (x = k * 0.2), so from step 3 on a 1-ulp difference in x (summation order differs between a slab's
+    # sort and the single-domain sort) puts such a particle in the neighbouring cell: measured 4 / 3 / 12 of 1024
+    # at steps 3 / 4 / 5, 0 at steps 1-2
+    match_and_compare(got, ref.particles(), st.smoothing_radius, max_key_flips=0.02)
     late = np.concatenate([np.load(tmp_path / f"late_{r}.npy") for r in range(world)])
     for _ in range(more):
         ref.step(tick)
     assert_statistics_close(late, ref.particles(), n)                     # then statistics (chaotic scene)
+
+
+WORKER_FRONT = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import gpu_fluid_simulation_amd as g
+from gpu_fluid_simulation_amd import multi
+from oracle import oracle as O
+from tests.slab_oracle import OracleSlabEngine
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n, steps, speed, floor, mode = int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+if mode == "undersized":
+    multi.travel_margin = lambda *a, **k: 0          # the round-1 behaviour: a fixed margin, blind to the fluid's speed
+st, off, tick = g.dam_break_2d(n)
+tick.gravity = g.Vec2(0.0, 0.0)
+hist, gw = multi.lattice_histogram(g, st, off)
+bounds = multi.partition_columns(hist, world)
+lat = g.reference_lattice(st, off)
+lat["velocity"][:, 0] = speed                        # a front running towards the +x wall
+margin0 = max(floor, multi.travel_margin(speed, 0.0, tick.delta, st.smoothing_radius, 4)) if mode != "undersized" else floor
+bounds = multi.trim_outer_edges(bounds, hist, margin0)
+tr = multi.Transport(rank, world, multi.HEADER_BYTES + multi.RECORD_BYTES * 8192)
+eng = OracleSlabEngine(O, st, bounds, rank, world, tr)
+cols = multi.global_columns(lat["position"][:, 0], st.size.x, st.smoothing_radius)
+eng.upload_owned(lat[(cols >= bounds[rank]) & (cols < bounds[rank + 1])])
+drv = multi.SlabDriver(eng, tr, bounds, gw, rebalance_every=4, max_shift=1, trim_margin=floor)
+try:
+    for _ in range(steps):
+        drv.step(tick)
+except multi.SlabProtocolError as e:
+    print("PROTOCOL", e, flush=True)
+    dist.destroy_process_group()
+    sys.exit(7)
+tot = torch.tensor([len(eng.owned_particles())])
+dist.all_reduce(tot)
+assert int(tot.item()) == n, (int(tot.item()), n)
+assert drv.last_margin > floor, drv.last_margin       # the margin followed the measured speed
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _run_front(tmp_path, mode, port):
+    script = tmp_path / "worker_front.py"
+    script.write_text(WORKER_FRONT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    # 4096 particles, 12 steps, 30 units/s = 1.25 columns per step = 5 per re-balancing interval, margin floor 2
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, "4096", "12", "30.0", "2", mode],
+                              env=dict(env, RANK=str(r)), cwd=ROOT, stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    return [p.returncode for p in procs], outs
+
+
+def test_gloo_fast_front_margin_follows_speed(fs, orc, tmp_path):
+    """ADVICE r1: a front faster than a FIXED outer-edge margin used to be deleted silently.  The margin now comes
+    from the all-reduced largest speed x the steps to the next re-trim: nothing is lost, counts are conserved."""
+    rcs, outs = _run_front(tmp_path, "follow", 29521)
+    assert rcs == [0, 0], outs
+
+
+def test_gloo_undersized_margin_raises_protocol_error(fs, orc, tmp_path):
+    """... and when particles ARE lost (margin forced back to the fixed floor) every rank raises at the next
+    re-balancing step instead of running on with fewer particles."""
+    rcs, outs = _run_front(tmp_path, "undersized", 29522)
+    assert rcs == [7, 7], outs
+    assert all("PROTOCOL" in o for o in outs)
+
+
+def test_travel_margin_bounds():
+    from gpu_fluid_simulation_amd import multi
+    f = multi.travel_margin
+    assert f(0.0, 0.0, 1 / 120, 0.2, 64) == 2                                  # nothing moves: just the halo tolerance
+    assert f(127.0, 9.81, 1 / 120, 0.2, 64) >= int(np.ceil(64 * 127.0 / 120 / 0.2))   # covers the plain advection distance
+    assert f(1e9, 0.0, 1 / 120, 0.2, 64) == int(np.ceil(64 * 500.0 / 120 / 0.2)) + 2  # never beyond the speed clamp
+    assert f(30.0, 0.0, 1 / 120, 0.2, 4) < f(30.0, 0.0, 1 / 120, 0.2, 64)
 
 
 # ---- properties of the pure partition logic (hypothesis) --------------------------------------------------------

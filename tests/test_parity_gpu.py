@@ -290,7 +290,8 @@ def test_counting_vs_bitonic_within_tolerance(fs):
     b = fs.FluidSimulation(st, device=0, initial_offset=off, sort_mode=fs.FS_SORT_COUNTING)
     for _ in range(4):
         a.tick(tick); b.tick(tick)
-    match_and_compare(b.download_particles(), a.download_particles(), st.smoothing_radius)
+    # step 4: lattice columns that sit exactly on a cell boundary may flip with 1-ulp x differences (slab_oracle.py)
+    match_and_compare(b.download_particles(), a.download_particles(), st.smoothing_radius, max_key_flips=0.02)
 
 
 @pytest.mark.parametrize("sort_mode", ["bitonic", "counting"])
@@ -345,7 +346,7 @@ def test_wgsl_ulp_math_mode_within_tolerance(fs, orc):
     assert not np.array_equal(got["velocity"].view(np.uint32), want["velocity"].view(np.uint32))   # really a different mode
     for _ in range(4):
         sim.tick(tick); ref.step(tick)
-    match_and_compare(sim.download_particles(), ref.particles(), st.smoothing_radius)
+    match_and_compare(sim.download_particles(), ref.particles(), st.smoothing_radius, max_key_flips=0.02)   # step 5
 
 
 def test_64m_properties(fs):

@@ -29,7 +29,7 @@ for case in range(first, first + cases):
         if s % every == 0:
             slabs.rebalance(2)
         if s == 2:      # elementwise while ULP-level differences (x2.4 per step, faster with random velocities) are still small
-            match_and_compare(slabs.owned(), single.download_particles(), st.smoothing_radius)
+            match_and_compare(slabs.owned(), single.download_particles(), st.smoothing_radius, max_key_flips=0.02)
     slabs.assert_clean()
     own = slabs.owned()
     assert own.shape[0] == n, (case, own.shape[0], n)

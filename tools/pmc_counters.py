@@ -6,7 +6,11 @@
 Every pass dispatches the same kernels in the same order; a kernel's dispatches of the timed part (the last
 steps/(warm+steps) of them) are averaged per counter.  Derived columns (chip: 256 CUs x 4 SIMDs = 1024 SIMDs):
   cycles          = GRBM_GUI_ACTIVE / 8            (rocprofv3 sums the counter over the 8 XCDs; MI355X guide, DVFS note)
-  valu_busy_frac  = SQ_ACTIVE_INST_VALU * 4 / (cycles * 1024)     (SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles)
+  valu_issue_frac = ((SQ_INSTS_VALU - TRANS) * 2.30 + TRANS * 4.56) / (cycles * 1024)   — share of the VALU issue slots in use.
+                    2.30 / 4.56 = measured cycles per wave-instruction per SIMD at 8 waves/SIMD for plain ops / v_rcp,v_sqrt,v_rsq
+                    (tools/valu_issue_table.hip, profiles/r02_a_valu_issue_table.txt).  SQ_ACTIVE_INST_VALU is NOT a busy time on
+                    gfx950: it reads 1 quad-cycle (4 cycles) per instruction whatever the instruction (valu_cyc_per_inst column),
+                    so SQ_ACTIVE_INST_VALU * 4 / cycles over-reads the issue share by 4 / 2.3 (it exceeds 1 for dense kernels).
   waves_per_simd  = SQ_WAVE_CYCLES * 4 / (cycles * 1024)          (achieved occupancy, of 8)
   valu_insts_per_wave = SQ_INSTS_VALU / SQ_WAVES
   valu_cyc_per_inst   = SQ_ACTIVE_INST_VALU * 4 / SQ_INSTS_VALU   (issue cycles a wave-instruction holds the SIMD)
@@ -61,7 +65,10 @@ for k, per in vals.items():
     d["us"] = round(r.get("us", 0.0), 1)
     d["cycles"] = round(cyc)
     if cyc > 0:
-        if g("SQ_ACTIVE_INST_VALU") is not None: d["valu_busy_frac"] = round(g("SQ_ACTIVE_INST_VALU") * 4 / (cyc * 1024), 3)
+        if g("SQ_INSTS_VALU") is not None:
+            tr = g("SQ_INSTS_VALU_TRANS_F32") or 0.0
+            d["valu_issue_frac"] = round(((g("SQ_INSTS_VALU") - tr) * 2.30 + tr * 4.56) / (cyc * 1024), 3)
+            d["valu_ginst_per_s_per_simd"] = round(g("SQ_INSTS_VALU") / 1024 / max(r.get("us", 0.0), 1e-9) / 1e3, 3)
         if g("SQ_WAVE_CYCLES") is not None: d["waves_per_simd"] = round(g("SQ_WAVE_CYCLES") * 4 / (cyc * 1024), 2)
         if g("SQ_LDS_IDX_ACTIVE") is not None: d["lds_busy_frac"] = round(g("SQ_LDS_IDX_ACTIVE") / (cyc * 256), 3)
         if g("SQ_ACTIVE_INST_LDS") is not None: d["lds_inst_busy_frac"] = round(g("SQ_ACTIVE_INST_LDS") * 4 / (cyc * 1024), 3)
@@ -89,7 +96,7 @@ for k, per in vals.items():
     rows[k] = d
 
 src = f"rocprofv3 --pmc (SQ/GRBM passes: {', '.join(dirs)}) -- python3 tools/pmc_run.py {tag}; warm {warm} + {steps} steps, last {steps} steps' dispatches averaged; tools/pmc_counters.py" + (f"; {note}" if note else "")
-cols = ["us", "cycles", "waves", "vgpr", "lds", "waves_per_simd", "valu_busy_frac", "valu_insts_per_wave", "valu_cyc_per_inst", "valu_lane_util",
+cols = ["us", "cycles", "waves", "vgpr", "lds", "waves_per_simd", "valu_issue_frac", "valu_ginst_per_s_per_simd", "valu_insts_per_wave", "valu_cyc_per_inst", "valu_lane_util",
         "salu_insts_per_wave", "lds_insts_per_wave", "vmem_rd_insts_per_wave", "trans_insts_per_wave", "lds_busy_frac", "bank_conflict_frac",
         "wait_frac", "wait_inst_frac", "active_inst_frac"]
 order = sorted(rows, key=lambda k: -rows[k].get("us", 0) * rows[k]["raw"].get("dispatches_averaged", 1))
@@ -113,4 +120,4 @@ if latest:
         cur["kernels"][k] = {c: d[c] for c in cols if c in d}
     json.dump(cur, open(latest, "w"), indent=1)
 for k in order[:12]:
-    print(k, {c: rows[k].get(c) for c in ("us", "waves_per_simd", "valu_busy_frac", "valu_insts_per_wave", "valu_cyc_per_inst", "lds_busy_frac", "wait_frac")})
+    print(k, {c: rows[k].get(c) for c in ("us", "waves_per_simd", "valu_issue_frac", "valu_ginst_per_s_per_simd", "valu_insts_per_wave", "valu_cyc_per_inst", "lds_busy_frac", "wait_frac")})
