@@ -110,6 +110,7 @@ struct fs_sim {
     DevArray<float> rho;
     DevArray<float2> rho2;          // {density, RN(1/density)}: what the force pass gathers per neighbour
     DevArray<uint32_t> key;
+    DevArray<unsigned char> safe;   // per sorted particle: coordinates / velocity inside the exact-quotient ranges (fs_device.h)
     DevArray<fsd::u64> pairs;
     DevArray<uint32_t> sort_dirty;  // per-tile flags of the bitonic sort
     DevArray<uint32_t> csort;       // scratch of the counting sort (FS_SORT_COUNTING)
@@ -148,7 +149,7 @@ struct fs_sim {
 
     void release() {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release(); rho2.release();
-        key.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
+        key.release(); safe.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
         owned.release(); flags.release(); blockcnt.release(); blockoff.release(); slab_counters.release();
         hist.release();
@@ -245,7 +246,10 @@ fsd::StepParams make_params(const fs_sim& s) {
     P.div_h2 = s.div_h2;
     // div_by_rcp's guards assume dst <= ~h <= 2^19 (fs_device.h); FS_NO_SHAREDIV=1 keeps every `/` a true division
     static const bool no_sharediv = getenv("FS_NO_SHAREDIV") != nullptr;
-    P.share_div = (!no_sharediv && s.div_2h3.ok && s.div_h2.ok && s.rcp_ok && s.sqrt_ok && P.h >= 0x1p-19f && P.h <= 0x1p19f) ? 1 : 0;
+    // ... and the per-particle "safe operand" classification bounds the pressure numerators only if h * spiky <= 2^19
+    const float hspiky = std::fabs(P.h * P.spiky);
+    P.share_div = (!no_sharediv && s.div_2h3.ok && s.div_h2.ok && s.rcp_ok && s.sqrt_ok && P.h >= 0x1p-19f && P.h <= 0x1p19f &&
+                   hspiky <= FS_HSPIKY_HI) ? 1 : 0;
     P.col_origin = 0;
     P.own_lo = 0; P.own_hi = s.grid_w;
     P.grid_w_global = s.grid_w;
@@ -360,9 +364,9 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     }
     if (prof) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, s->key.p, s->cs.p,
-                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap, counting);
+                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, counting);
     if (prof) FS_HIP(hipEventRecord(ev[3], st));
-    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p, s->rho2.p);
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, s->pos.p, s->vel.p);
@@ -435,7 +439,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1));
@@ -764,7 +768,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->owned.alloc(cap)); FS_TRY(s->flags.alloc(cap));
@@ -879,9 +883,9 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     if (ev) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
                              s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,
-                             s->slab_counters.p, counting);
+                             s->slab_counters.p, s->safe.p, counting);
     if (ev) FS_HIP(hipEventRecord(ev[3], st));
-    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->rho.p, s->rho2.p);
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p);
     if (ev) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, s->pos.p, s->vel.p);

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
                                                            unsigned char* __restrict__ owned,
                                                            uint32_t* __restrict__ cs, uint32_t* __restrict__ start_ref,
                                                            GapEntry* __restrict__ work, uint32_t* __restrict__ counter,
-                                                           uint32_t work_cap, uint32_t* __restrict__ n_live_out) {
+                                                           uint32_t work_cap, uint32_t* __restrict__ n_live_out,
+                                                           unsigned char* __restrict__ safe) {
     const uint32_t i = blockIdx.x * SL_BLOCK + threadIdx.x;
     if (i >= cap) return;
     const u64 pr = pairs[i];
@@ -215,8 +216,10 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
     const float2 v = vel_in[src];
     pos_s[i] = p;
     vel_s[i] = v;
-    pred_s[i] = predict_pos(P, p, v);
+    const float2 pd = predict_pos(P, p, v);
+    pred_s[i] = pd;
     key_s[i] = key;
+    safe[i] = kin_safe(pd, v) ? 1 : 0;        // fs_device.h "safe operand" classification, finished by k_density
     const uint32_t cy = key / P.grid_w;
     const int32_t cxg = (int32_t)(key - cy * P.grid_w) + P.col_origin;
     owned[i] = (cxg >= (int32_t)P.own_lo && cxg < (int32_t)P.own_hi) ? 1 : 0;
@@ -345,14 +348,14 @@ void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots
 void launch_slab_reorder(hipStream_t st, const StepParams& P, uint32_t cap, const u64* pairs, const float2* pos_in,
                          const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s,
                          unsigned char* owned, uint32_t* cs, uint32_t* start_ref, void* work, uint32_t* counter,
-                         uint32_t work_cap, uint32_t* n_live_out, bool cs_ready) {
+                         uint32_t work_cap, uint32_t* n_live_out, unsigned char* safe, bool cs_ready) {
     if (cs_ready) {   // counting sort: table and live count already exist
         hipLaunchKernelGGL(k_slab_reorder<false>, dim3(nb(cap)), dim3(SL_BLOCK), 0, st, P, cap, pairs, pos_in, vel_in,
-                           pos_s, vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out);
+                           pos_s, vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out, safe);
         return;
     }
     hipLaunchKernelGGL(k_slab_reorder<true>, dim3(nb(cap)), dim3(SL_BLOCK), 0, st, P, cap, pairs, pos_in, vel_in, pos_s,
-                       vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out);
+                       vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out, safe);
     launch_fill_gaps(st, cs, work, counter, work_cap);
 }
 

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
                                                       float2* __restrict__ vel_s, float2* __restrict__ pred_s,
                                                       uint32_t* __restrict__ key_s, uint32_t* __restrict__ cs,
                                                       uint32_t* __restrict__ start_ref, GapEntry* __restrict__ work,
-                                                      uint32_t* __restrict__ counter, uint32_t work_cap) {
+                                                      uint32_t* __restrict__ counter, uint32_t work_cap,
+                                                      unsigned char* __restrict__ safe) {
     const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
     if (i >= P.n) return;
     const u64 pr = pairs[i];
@@ -53,8 +54,10 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
     const float2 v = vel_in[src];
     pos_s[i] = p;
     vel_s[i] = v;
-    pred_s[i] = predict_pos(P, p, v);   // same expression as the key generation in the sort -> same bits
+    const float2 pd = predict_pos(P, p, v);   // same expression as the key generation in the sort -> same bits
+    pred_s[i] = pd;
     key_s[i] = key;
+    safe[i] = kin_safe(pd, v) ? 1 : 0;        // fs_device.h "safe operand" classification, finished by k_density
 
     const uint32_t kc = key < P.ncell ? key : P.ncell;   // clamp for table writes only
     if (i == 0) {
@@ -130,7 +133,8 @@ __device__ __forceinline__ float density_term(const StepParams& P, float h2, flo
 __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2* __restrict__ pred,
                                                       const uint32_t* __restrict__ cs,
                                                       const uint32_t* __restrict__ start_ref,
-                                                      const u64* __restrict__ pairs, float* __restrict__ rho_out,
+                                                      const u64* __restrict__ pairs, const unsigned char* __restrict__ safe,
+                                                      float* __restrict__ rho_out,
                                                       float2* __restrict__ rho2_out) {
     __shared__ float2 s_pred[3][NB_TILE];
     __shared__ uint32_t s_red[24];
@@ -185,7 +189,12 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
     rho = fmaxf(rho, 1.19209290e-07f);                          // funcs.wgsl:202
     rho = fmaxf(rho, 0.1f);                                     // compute.wgsl:70
     rho_out[i] = rho;
-    rho2_out[i] = make_float2(rho, __fdiv_rn(1.0f, rho));       // the force pass divides by neighbours' densities
+    // {rho, +-RN(1/rho)}: the force pass divides by neighbours' densities; the sign carries the particle's
+    // "safe operand" classification (fs_device.h) — negative sends every pair it takes part in to true divisions
+    const float press = P.pressure_k * (rho - P.rest_density);  // the expression the force pass evaluates
+    const bool ok = safe[i] != 0 && rho <= FS_RCP_HI && fabsf(press) <= FS_PRESSURE_HI;
+    const float y = __fdiv_rn(1.0f, rho);
+    rho2_out[i] = make_float2(rho, ok ? y : -y);
 }
 
 // ---------------------------------------------------------- force + integrate
@@ -266,21 +275,34 @@ __device__ __forceinline__ ForceTerms force_terms(const StepParams& P, const flo
     return T;
 }
 
+// The exact body behind a real call (FS_SLOW_NOINLINE): the hot loops then carry only the call's argument set-up
+// instead of the whole true-division body in their register allocation.
+#ifdef FS_SLOW_NOINLINE
+__device__ __attribute__((noinline)) void force_terms_exact_call(const StepParams* P, float2 me, float2 mv, float pressure,
+                                                                  float2 q, float2 nv, float nrho, uint32_t* seed,
+                                                                  ForceTerms* out) {
+    *out = force_terms<false>(*P, me, mv, pressure, q, nv, nrho, *seed);
+}
+#endif
+
 // The same terms with ONE true division per denominator (1/dst, 1/nrho) and div_by_rcp() for the
-// seven quotients — bit-identical to force_terms<false> whenever `ok` comes back true (operands
+// seven quotients — bit-identical to force_terms<false> whenever `good` comes back all-ones (operands
 // inside the proven range, fs_device.h).  Straight-line: no PRNG path, no tiny-distance path;
 // those (and any out-of-range operand) clear the lane's bit in `good`, and the caller re-evaluates
 // the pair with the exact body for the whole wave when any active lane's bit is missing.
+// Guards per pair: r2 >= 2^-40 (excludes r2 == 0 = the PRNG path, NaN and div_const's tiny range; r2 <= h*h
+// because the scan admitted it, and the host only enables this path for h <= 2^19: the proven sqrt range), the
+// neighbour's "safe operand" sign (fs_device.h; the lane's own is folded in by the caller), and the lower bound
+// of the two pressure numerators.
+__device__ __forceinline__ wave_mask num_lo_ok(float a) { return wm(fabsf(a) >= 0x1p-60f) | wm(a == 0.0f); }   // NaN: 0
 __device__ __forceinline__ ForceTerms force_terms_shared(const StepParams& P, const float2 me, const float2 mv,
                                                          float pressure, const float2 q, const float2 nv,
-                                                         const float2 nd /* {density, RN(1/density)} */, wave_mask& good) {
+                                                         const float2 nd /* {density, +-RN(1/density)} */, wave_mask& good) {
     const float h = P.h;
     const float nrho = nd.x, yrho = nd.y;
     const float ox = q.x - me.x, oyv = q.y - me.y;
     const float r2 = ox * ox + oyv * oyv;
-    // r2 >= 2^-40 excludes r2 == 0 (PRNG path), NaN and div_const's tiny range; r2 <= h*h because the
-    // scan admitted it, and the host only enables this path for h <= 2^19: the proven sqrt range
-    good = wm(r2 >= FS_SQRT_LO) & rcp_num_lo_ok(ox) & rcp_num_lo_ok(oyv) & wm(nrho <= FS_RCP_HI);   // nrho >= 0.1 (k_density)
+    good = wm(r2 >= FS_SQRT_LO) & wm(yrho > 0.0f);
     const float dst = sqrt_rn_fast(r2);                                 // in [2^-20, ~h]
     const float ydst = rcp_rn_fast(dst);
     const float dx = div_by_rcp(ox, dst, ydst);
@@ -291,7 +313,7 @@ __device__ __forceinline__ ForceTerms force_terms_shared(const StepParams& P, co
     const float shared = (pressure + npress) * 0.5f;
     const float apx = dx * kern * shared, apy = dy * kern * shared;
     const float dvx = nv.x - mv.x, dvy = nv.y - mv.y;
-    good &= rcp_num_ok(apx) & rcp_num_ok(apy) & rcp_num_ok(dvx) & rcp_num_ok(dvy);
+    good &= num_lo_ok(apx) & num_lo_ok(apy);
     ForceTerms T;
     T.px = div_by_rcp(apx, nrho, yrho);
     T.py = div_by_rcp(apy, nrho, yrho);
@@ -331,8 +353,10 @@ template <bool STAGED, bool FAST>
 __device__ __forceinline__ void force_sweep_chunks(const StepParams& P, const RowRanges& R, const uint32_t* blo,
                                                    uint32_t ii, const float2 me, const float2 mv, float pressure,
                                                    const float2* __restrict__ pred, const float2* __restrict__ vel_s,
-                                                   const float2* __restrict__ rho2, const float2* s_flat, ForceAcc& A) {
+                                                   const float2* __restrict__ rho2, const float2* s_flat, bool me_ok,
+                                                   ForceAcc& A) {
     const float lim = P.sqr_radius;
+    const wave_mask me_okm = wm(me_ok);      // the lane's own "safe operand" classification (all lanes active here)
     // plain registers: as arrays the row selects below become dynamic indexing, which the compiler
     // serves from scratch / promoted LDS
     uint32_t lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2], hi0 = R.hi[0], hi1 = R.hi[1], hi2 = R.hi[2];
@@ -391,8 +415,14 @@ __device__ __forceinline__ void force_sweep_chunks(const StepParams& P, const Ro
                         T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
                     } else {
                         wave_mask good = 0;
-                        if (P.share_div) T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good);
-                        if (good != wm(true)) T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
+                        if (P.share_div) { T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good); good &= me_okm; }
+                        if (good != wm(true)) {
+#ifdef FS_SLOW_NOINLINE
+                            force_terms_exact_call(&P, me, mv, pressure, q0, v0, d0.x, &A.seed, &T0);
+#else
+                            T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
+#endif
+                        }
                     }
                     A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
                 }
@@ -415,7 +445,7 @@ template <bool FAST>
 __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const RowRanges& R, const uint32_t* blo,
                                                   uint32_t ii, const float2 me, const float2 mv, float pressure,
                                                   const float2* __restrict__ vel_s, const float2* __restrict__ rho2,
-                                                  const float2* s_flat /* [3][NBF_ROW] */, ForceAcc& A) {
+                                                  const float2* s_flat /* [3][NBF_ROW] */, bool me_ok, ForceAcc& A) {
     uint32_t m[3], la[3];                    // masks (bit 31-t <=> candidate lo+t), flat LDS index of lo
     const float lim = P.sqr_radius;
 #pragma unroll
@@ -447,6 +477,7 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
     float2 qn = make_float2(0.0f, 0.0f), vn = qn, dn = qn;
     bool have = false;
     uint32_t m0 = m[0], m1 = m[1], m2 = m[2];
+    const wave_mask me_okm = wm(me_ok);      // the lane's own "safe operand" classification (all lanes active here)
 #define FS_FETCH_NEXT()                                                                                              \
     do {                                                                                                             \
         have = (m0 | m1 | m2) != 0u;                                                                                 \
@@ -477,8 +508,14 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
                 T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
             } else {
                 wave_mask good = 0;
-                if (P.share_div) T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good);
-                if (good != wm(true)) T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);   // rare, wave-uniform
+                if (P.share_div) { T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good); good &= me_okm; }
+                if (good != wm(true)) {             // rare, wave-uniform
+#ifdef FS_SLOW_NOINLINE
+                    force_terms_exact_call(&P, me, mv, pressure, q0, v0, d0.x, &A.seed, &T0);
+#else
+                    T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
+#endif
+                }
             }
             A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
         }
@@ -489,8 +526,11 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
 // amdgpu_waves_per_eu(8, 8): with the chunked sweep inlined next to the mask sweep the allocator would take
 // 83 VGPRs (5 waves/SIMD) and the common path loses 9 %; capped at 64 it spills in the rarely taken
 // branches instead (measured: 0.77 vs 0.86 ms in the bench window, 2.67 vs 2.82 ms in the dense regime).
+#ifndef FS_FORCE_WAVES
+#define FS_FORCE_WAVES 8
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_force(StepParams P, const float2* __restrict__ pos_s,
+__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FORCE_WAVES, FS_FORCE_WAVES))) void k_force(StepParams P, const float2* __restrict__ pos_s,
                                                     const float2* __restrict__ vel_s,
                                                     const float2* __restrict__ pred, const float2* __restrict__ rho2,
                                                     const uint32_t* __restrict__ cs,
@@ -509,7 +549,9 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
     const float2 me = pred[ii];
     const float2 mv = vel_s[ii];
-    const float mrho = rho2[ii].x;
+    const float2 mrec = rho2[ii];
+    const float mrho = mrec.x;
+    const bool me_ok = mrec.y > 0.0f;               // this particle's "safe operand" classification (fs_device.h)
     const float pressure = P.pressure_k * (mrho - P.rest_density);      // funcs.wgsl:152-154
     ForceAcc A;
     A.fpx = A.fpy = A.fvx = A.fvy = 0.0f;
@@ -538,11 +580,11 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
         __syncthreads();
         const bool long_row = R.hi[0] - R.lo[0] > 32u || R.hi[1] - R.lo[1] > 32u || R.hi[2] - R.lo[2] > 32u;
         if (!__any(long_row))
-            force_sweep_masks<FAST>(P, R, blo, ii, me, mv, pressure, vel_s, rho2, &s_pred[0][0], A);
+            force_sweep_masks<FAST>(P, R, blo, ii, me, mv, pressure, vel_s, rho2, &s_pred[0][0], me_ok, A);
         else
-            force_sweep_chunks<true, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], A);
+            force_sweep_chunks<true, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], me_ok, A);
     } else {
-        force_sweep_chunks<false, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], A);
+        force_sweep_chunks<false, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], me_ok, A);
     }
     if (!live) return;
     const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
@@ -742,21 +784,21 @@ static inline uint32_t nblk(uint32_t n) { return (n + FS_BLOCK - 1) / FS_BLOCK; 
 
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
-                    void* work, uint32_t* counter, uint32_t work_cap, bool cs_ready) {
+                    void* work, uint32_t* counter, uint32_t work_cap, unsigned char* safe, bool cs_ready) {
     if (cs_ready) {   // counting sort already produced the dense table
         hipLaunchKernelGGL(k_reorder<false>, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pairs, pos_in, vel_in, pos_s,
-                           vel_s, pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap);
+                           vel_s, pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap, safe);
         return;
     }
     hipLaunchKernelGGL(k_reorder<true>, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pairs, pos_in, vel_in, pos_s, vel_s,
-                       pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap);
+                       pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap, safe);
     hipLaunchKernelGGL(k_fill_gaps, dim3(1024), dim3(FS_BLOCK), 0, st, cs, (const GapEntry*)work, counter, work_cap);
 }
 
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
-                    const uint32_t* start_ref, const u64* pairs, float* rho, float2* rho2) {
+                    const uint32_t* start_ref, const u64* pairs, const unsigned char* safe, float* rho, float2* rho2) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
-    hipLaunchKernelGGL(k_density, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, rho, rho2);
+    hipLaunchKernelGGL(k_density, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2);
 }
 
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,

@@ -136,23 +136,25 @@ def test_slot_capacity_overflow_is_counted(fs):
     (multi.SlabDriver raises on it), and a capacity sized by multi.slab_capacities never gets there."""
     n = 16384
     st, off, tick = fs.dam_break_2d(n)
-    recv = 2048
-    tight = InProcessSlabs(fs, st, off, 2, cap=n // 2 + 64 + 2 * recv, recv=recv)       # main = owned + 64: no room for ghosts
-    tight.step(tick)
-    live = [s.counters()["n_live"] for s in tight.sims]
-    assert max(live) > n // 2 + 64, live                   # the step left more live records than main slots
-    tight.step(tick)                                       # ... which the next pack must notice
-    assert sum(s.counters()["overflow"] for s in tight.sims) > 0
     from gpu_fluid_simulation_amd import multi
     gh = int(np.ceil(np.float32(st.size.y) / np.float32(st.smoothing_radius))) + 2
     cap, rc = multi.slab_capacities(n, 2, gh)
     roomy = InProcessSlabs(fs, st, off, 2, cap=cap, recv=rc)
+    owned_max = max(s.counters()["n_live"] for s in roomy.sims)       # before the first step: the uploaded owned particles
     for _ in range(12):
         roomy.step(tick)
     roomy.assert_clean()
     assert roomy.owned().shape[0] == n
+    recv = 2048
+    main = owned_max + 64                                  # room for the owned share, none for the ~500 ghosts
+    tight = InProcessSlabs(fs, st, off, 2, cap=main + 2 * recv, recv=recv)
+    tight.step(tick)
+    live = [s.counters()["n_live"] for s in tight.sims]
+    assert max(live) > main, (live, main)                  # the step left more live records than main slots
+    tight.step(tick)                                       # ... which the next pack must notice
+    assert sum(s.counters()["overflow"] for s in tight.sims) > 0
     with pytest.raises(fs.FluidSimError):                  # more owned particles than main slots: rejected up front
-        tight.sims[0].upload_owned(tight.initial[: n // 2 + 65])
+        tight.sims[0].upload_owned(tight.initial[: main + 1])
 
 
 def _cell_histograms_equal(a, b, ncell):
