@@ -29,6 +29,16 @@ def u32sat(x):
     return int(x)
 
 
+def wmax(a, b):
+    """WGSL max() on floats: "If one operand is a NaN, the other is returned" (Python's max() would keep a NaN
+    first operand)."""
+    if a != a:
+        return b
+    if b != b:
+        return a
+    return b if a < b else a
+
+
 def sign(x):
     return f(1.0) if x > 0 else (f(-1.0) if x < 0 else f(0.0))
 
@@ -102,7 +112,7 @@ def step(parts, start_indices, u):
                     r2 = dx * dx + dy * dy
                     kern = f(0.0) if r2 > h2 else norm * (h2 - r2) * (h2 - r2) * (h2 - r2)
                     rho = rho + u["mass"] * kern * f(1.0)
-        p["density"] = max(max(rho, EPS), f(0.1))
+        p["density"] = wmax(wmax(rho, EPS), f(0.1))           # funcs.wgsl:202, compute.wgsl:70
     snap = [dict(p) for p in parts]
     for pid, p in enumerate(snap):  # move
         pos = p["pred"]
@@ -155,6 +165,16 @@ def step(parts, start_indices, u):
         for a in (0, 1):
             v[a] = v[a] + ((fp[a] + fv[a]) / p["density"]) * u["dt"]
             v[a] = v[a] + u["gravity"][a] * u["dt"]
+        if u.get("mouse_state", 0) != 0:                      # compute.wgsl:99-108
+            pp = p["pred"]
+            diff = (u["mouse_pos"][0] - pp[0], u["mouse_pos"][1] - pp[1])
+            dist = np.sqrt(diff[0] * diff[0] + diff[1] * diff[1])
+            if dist <= u["mouse_radius"]:
+                d = ((diff[0] / dist) / dist, (diff[1] / dist) / dist)
+                ratio = dist / u["mouse_radius"]
+                ms = f(u["mouse_state"])
+                v[0] = v[0] + d[0] * u["mouse_power"] * ms * ratio
+                v[1] = v[1] + d[1] * u["mouse_power"] * ms * ratio
         if not (v[0] == v[0] and v[1] == v[1]):
             v = [f(0.0), f(0.0)]
         sp = np.sqrt(v[0] * v[0] + v[1] * v[1])
@@ -162,7 +182,25 @@ def step(parts, start_indices, u):
             v = [(v[0] / sp) * f(500.0), (v[1] / sp) * f(500.0)]
         for a in (0, 1):
             x[a] = x[a] + v[a] * u["dt"]
-        for a in (0, 1):  # zero force field assumed
+        tex = u.get("texture")                                # compute.wgsl:127-140 (force-field push-out)
+        if tex is not None:
+            pp = p["pred"]
+            ts = u["texture_size"]                            # (w, h) as f32, like the uniform
+            uv = ((pp[0] / u["bounds"][0]) * f(1.0) + f(0.5), (pp[1] / u["bounds"][1]) * f(1.0) + f(0.5))
+            px, py = u32sat(uv[0] * ts[0]), u32sat(uv[1] * ts[1])
+            ti = (py * u32sat(ts[0]) + px) & 0xFFFFFFFF
+            force = (f(tex[ti][0]), f(tex[ti][1])) if ti < len(tex) else (f(0.0), f(0.0))   # OOB read -> zero
+            if force[0] != 0 or force[1] != 0:
+                p2w = ((u["bounds"][0] * f(2.0)) / ts[0], (u["bounds"][1] * f(2.0)) / ts[1])
+                fw = (force[0] * p2w[0], force[1] * p2w[1])
+                ln = np.sqrt(force[0] * force[0] + force[1] * force[1])
+                nn = (force[0] / ln, force[1] / ln)
+                x[0] = x[0] + fw[0]
+                x[1] = x[1] + fw[1]
+                vn = v[0] * nn[0] + v[1] * nn[1]
+                v[0] = v[0] - (f(1.0) - u["damping"]) * vn * nn[0]
+                v[1] = v[1] - (f(1.0) - u["damping"]) * vn * nn[1]
+        for a in (0, 1):                                      # walls, compute.wgsl:143-153
             if abs(x[a]) > bs[a]:
                 x[a] = bs[a] * sign(x[a])
                 v[a] = v[a] * (f(-1.0) * u["damping"])

@@ -228,6 +228,110 @@ def test_oracle_matches_python_restatement(orc):
         assert np.array_equal(si, o.start_indices())
 
 
+def _pyref_uniform(u, f, **extra):
+    d = dict(bounds=(f(u.bounds.x), f(u.bounds.y)), h=f(u.smoothing_radius), dt=f(u.delta), grid_w=u.grid_w,
+             mass=f(u.particle_mass), pow_h8=f(np.float32(u.smoothing_radius) ** np.float32(8.0)),
+             k=f(u.pressure_constant), rho0=f(u.rest_density), frame=u.frame_time, sqr_radius=f(u.sqr_radius),
+             spiky=f(u.spiky_kernel_derivative), visc=f(u.viscosity_kernel),
+             visc_coeff=f(u.viscosity_coefficient), gravity=(f(u.gravity.x), f(u.gravity.y)),
+             damping=f(u.damping_factor), mouse_state=int(u.mouse_state), mouse_pos=(f(u.mouse_pos.x), f(u.mouse_pos.y)),
+             mouse_radius=f(u.mouse_force_radius), mouse_power=f(u.mouse_force_power),
+             texture_size=(f(u.texture_size.x), f(u.texture_size.y)))
+    d.update(extra)
+    return d
+
+
+def _run_both(orc, o, parts, tick, steps, texture=None):
+    """Step the C++ oracle and the pure-Python restatement side by side; everything must agree bit for bit."""
+    f = np.float32
+    gw, gh = o.grid_dims
+    si = np.zeros(gw * gh, dtype=np.uint32)
+    for s in range(steps):
+        o.step(tick)
+        u = g.Uniform.from_buffer_copy(o.uniform_bytes())
+        pyref.step(parts, si, _pyref_uniform(u, f, texture=texture))
+        got = o.particles()
+        assert [p["grid"] for p in parts] == got["grid"].tolist(), s
+        for i, p in enumerate(parts):
+            a = np.array([p["pos"][0], p["pos"][1], p["vel"][0], p["vel"][1], p["density"]], dtype=f).view(np.uint32)
+            b = np.array([got["position"][i][0], got["position"][i][1], got["velocity"][i][0], got["velocity"][i][1],
+                          got["density"][i]], dtype=f).view(np.uint32)
+            assert np.array_equal(a, b), (s, i, a, b)
+        assert np.array_equal(si, o.start_indices())
+    return o.particles()
+
+
+def _parts_of(view):
+    f = np.float32
+    return [dict(pos=(f(q["position"][0]), f(q["position"][1])), pred=(f(0), f(0)),
+                 vel=(f(q["velocity"][0]), f(q["velocity"][1])), density=f(0), grid=0) for q in view]
+
+
+def test_oracle_matches_python_restatement_mouse_and_walls(orc):
+    """compute.wgsl:99-108 (mouse impulse, both buttons) and :143-153 (wall clamp with damped reflection of a MOVING
+    particle): 150 particles thrown at the walls while the mouse pulls / pushes; 3 steps, bit for bit."""
+    f = np.float32
+    n = 150
+    st = g.SimulationSettings(n, 0.1, 0.2, (2.4, 2.0))
+    for state in (1, -1):
+        tick = g.default_tick_settings(gravity=(0.0, 9.81), mouse_state=state, mouse_pos=(0.3, -0.2),
+                                       mouse_force_radius=0.9, mouse_force_power=40.0)
+        o = orc.OracleSim(st)
+        rng = np.random.default_rng(5 + state)
+        v = o.particles_view()
+        v["position"] += rng.uniform(-0.03, 0.03, size=(n, 2)).astype(f)
+        v["predicted_position"] = v["position"]
+        v["velocity"] = rng.uniform(-40, 40, size=(n, 2)).astype(f)       # 0.33 units / step: walls within reach
+        out = _run_both(orc, o, _parts_of(v), tick, 3)
+        bs = np.array([1.2, 1.0], dtype=f)
+        assert (np.abs(out["position"]) == bs).any(), "no particle reached a wall: the bounce branch did not run"
+
+
+def test_oracle_matches_python_restatement_obstacle_field(orc):
+    """compute.wgsl:127-140: texture lookup at the predicted position, push-out by the field vector, damped removal
+    of the normal velocity — with a non-zero 16x12 field (zero in one corner, so both branches run)."""
+    f = np.float32
+    n = 120
+    st = g.SimulationSettings(n, 0.1, 0.2, (3.0, 2.4), (16, 12))
+    tick = g.default_tick_settings(gravity=(0.3, 9.81))
+    o = orc.OracleSim(st)
+    rng = np.random.default_rng(31)
+    v = o.particles_view()
+    v["position"] += rng.uniform(-0.03, 0.03, size=(n, 2)).astype(f)
+    v["predicted_position"] = v["position"]
+    v["velocity"] = rng.uniform(-3, 3, size=(n, 2)).astype(f)
+    tex = rng.uniform(-0.02, 0.02, size=(12, 16, 2)).astype(f)
+    tex[:6, :8] = 0.0
+    o.texture_view()[:] = tex
+    before = o.particles()["position"].copy()
+    out = _run_both(orc, o, _parts_of(v), tick, 3, texture=[(a, b) for a, b in tex.reshape(-1, 2)])
+    assert not np.array_equal(before, out["position"])
+    nz = (tex.reshape(-1, 2) != 0).any(axis=1).mean()
+    assert 0.2 < nz < 0.9
+
+
+def test_oracle_matches_python_restatement_prng_nan_and_clamp(orc):
+    """Coincident particles (r == 0 -> xorshift32 direction, compute.wgsl:211-212 + funcs.wgsl:129-149, and the
+    r == 0 viscosity constant funcs.wgsl:116), a NaN velocity (reset to 0, compute.wgsl:113-116) and a particle far
+    above the 500 speed clamp (:118-122); 2 steps, bit for bit."""
+    f = np.float32
+    n = 64
+    st = g.SimulationSettings(n, 0.1, 0.2, (3.0, 3.0))
+    tick = g.default_tick_settings(gravity=(0.0, 9.81))
+    o = orc.OracleSim(st)
+    v = o.particles_view()
+    v["position"][5] = v["position"][4]              # two coincident pairs
+    v["position"][41] = v["position"][40]
+    v["position"][42] = v["position"][40]            # ... and a coincident triple
+    v["predicted_position"] = v["position"]
+    v["velocity"][:] = 0
+    v["velocity"][10] = (np.nan, 1.0)
+    v["velocity"][20] = (9000.0, -7000.0)
+    out = _run_both(orc, o, _parts_of(v), tick, 2)
+    assert np.isfinite(out["velocity"]).all() and np.isfinite(out["position"]).all()
+    assert np.sqrt((out["velocity"].astype(np.float64) ** 2).sum(axis=1)).max() <= 500.001
+
+
 def test_stated_tolerance_against_f64_run(orc):
     """SURVEY.md §8c states the float tolerance for consumers that do not rely on bit equality: one step from an
     identical state with an identical permutation — density rel <= 1e-5, velocity / position abs <= 1e-4*h + rel
