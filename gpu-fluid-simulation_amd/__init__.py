@@ -217,6 +217,12 @@ class FluidSimulation:
         _check(self._lib, self._lib.fs_render_density(self._h, C.byref(view), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def export_handle(self, which=_abi.FS_EXPORT_PARTICLES):
+        """fs_export_handle: interprocess handle of the AoS particle view (switches on the live view) or of start_indices."""
+        h = _abi.MemHandle()
+        _check(self._lib, self._lib.fs_export_handle(self._h, int(which), C.byref(h)))
+        return h
+
     def particles_device_ptr(self):
         p = C.c_void_p()
         _check(self._lib, self._lib.fs_particles_device(self._h, C.byref(p)))
@@ -448,6 +454,28 @@ class ResizableBuffer:
             self.close()
         except Exception:
             pass
+
+
+class ImportedBuffer:
+    """Consumer side of fs_export_handle in another process: maps the exported device range (fs_import_open)."""
+
+    def __init__(self, handle_bytes, device=0):
+        self._lib = load_library()
+        self.handle = _abi.MemHandle.from_buffer_copy(handle_bytes)
+        self._p = C.c_void_p()
+        _check(self._lib, self._lib.fs_import_open(C.byref(self.handle), int(device), C.byref(self._p)))
+
+    def read(self, dtype, count=None, offset=0):
+        dtype = np.dtype(dtype)
+        count = int(self.handle.bytes // dtype.itemsize) if count is None else int(count)
+        out = np.empty(count, dtype=dtype)
+        _check(self._lib, self._lib.fs_import_read(self._p, int(offset), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def close(self):
+        if self._p.value:
+            _check(self._lib, self._lib.fs_import_close(self._p))
+            self._p = C.c_void_p()
 
 
 def generate_force_field(image, device=0):

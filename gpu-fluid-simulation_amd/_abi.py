@@ -165,6 +165,13 @@ FS_MATH_IEEE = 0
 FS_MATH_WGSL_ULP = 1
 
 PASS_NAMES = ("predict_key", "sort", "reorder", "density", "force")
+FS_EXPORT_PARTICLES = 0
+FS_EXPORT_START_INDICES = 1
+
+
+class MemHandle(C.Structure):
+    """fs_mem_handle (include/fluidsim.h): 80 bytes, safe to send to another process as raw bytes."""
+    _fields_ = [("ipc", C.c_uint8 * 64), ("bytes", C.c_uint64), ("device", C.c_int32), ("dmabuf_fd", C.c_int32)]
 
 # name -> (restype, argtypes).  Every symbol include/fluidsim.h declares.
 _P = C.c_void_p
@@ -195,6 +202,15 @@ PROTOTYPES = {
     "fs_profile_enable": (C.c_int, [_P, C.c_int]),
     "fs_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "fs_timed_steps": (C.c_int, [_P, C.POINTER(TickSettings), C.c_uint32, C.POINTER(C.c_double)]),
+    "fs_export_handle": (C.c_int, [_P, C.c_int, _P]),
+    "fs_import_open": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "fs_import_read": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),
+    "fs_import_close": (C.c_int, [_P]),
+    "fs_comm_unique_id": (C.c_int, [_P]),
+    "fs_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "fs_comm_destroy": (None, [_P]),
+    "fs_slab_exchange": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "fs_comm_allreduce": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int]),
     "fs_slab_create": (C.c_int, [C.POINTER(Settings), C.c_int, C.POINTER(SlabConfig), C.POINTER(_P)]),
     "fs_slab_upload_owned": (C.c_int, [_P, _P, C.c_size_t]),
     "fs_slab_set_window": (C.c_int, [_P, C.c_uint32, C.c_uint32]),

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfluidsim_hip.so")
-SOURCES = ["engine.hip", "buffer.hip", "kernels_step.hip", "kernels_sort.hip", "kernels_slab.hip", "kernels_csort.hip", "kernels_field.hip", "sim3d.hip"]
+SOURCES = ["engine.hip", "comm.hip", "buffer.hip", "kernels_step.hip", "kernels_sort.hip", "kernels_slab.hip", "kernels_csort.hip", "kernels_field.hip", "sim3d.hip"]
 HEADERS = ["fs_device.h", "fs_kernels.h", os.path.join("..", "..", "include", "fluidsim.h")]
 FLAGS = [
     "--offload-arch=gfx950",
@@ -71,7 +71,7 @@ def build(force=False, verbose=True, out=None, extra_flags=()):
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     if force or procs or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -94,7 +94,7 @@ def _build_variant(hipcc, out, extra, verbose):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
     return out
 
 

@@ -121,6 +121,8 @@ struct fs_sim {
     DevArray<uint32_t> counter;
     uint32_t work_cap = 0;
     DevArray<fs_particle> aos;      // lazily allocated 32-byte view
+    bool aos_live = false;          // a hand-off is registered: the force pass writes the AoS records itself
+    uint32_t aos_tick = 0xFFFFFFFFu;   // tick whose state the AoS view holds (only meaningful with aos_live)
 
     fsd::ConstDiv div_2h3{}, div_h2{};   // exact constant divisions of the force pass, proven at create
     bool rcp_ok = false, sqrt_ok = false; // rcp_rn_fast / sqrt_rn_fast proven on this device at create
@@ -369,7 +371,8 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p);
+                      s->tex.p, s->pos.p, s->vel.p, s->aos_live ? (void*)s->aos.p : nullptr);
+    if (s->aos_live) s->aos_tick = s->tick;
     if (prof) {
         FS_HIP(hipEventRecord(ev[5], st));
         s->prof_pending += 1;
@@ -511,8 +514,11 @@ fs_status fs_particles_device(fs_sim* s, const fs_particle** out) {
     if (!s || !out) return fail(FS_ERR_INVALID, "null argument");
     FS_HIP(hipSetDevice(s->device));
     if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
-    fsd::launch_export_aos(s->stream, s->n, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p, s->aos.p);
-    FS_HIP(hipGetLastError());
+    if (!(s->aos_live && s->aos_tick == s->tick && s->tick != 0)) {   // live view: the force pass already wrote it
+        fsd::launch_export_aos(s->stream, s->n, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p, s->aos.p);
+        FS_HIP(hipGetLastError());
+        if (s->aos_live) s->aos_tick = s->tick;
+    }
     *out = s->aos.p;
     return FS_OK;
 }
@@ -559,6 +565,7 @@ fs_status fs_upload_particles(fs_sim* s, const fs_particle* src, size_t n) {
     if (n) FS_HIP(hipMemcpyAsync(s->aos.p, src, n * sizeof(fs_particle), hipMemcpyHostToDevice, s->stream));
     fsd::launch_import_aos(s->stream, (uint32_t)n, s->aos.p, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p);
     FS_HIP(hipStreamSynchronize(s->stream));
+    s->aos_tick = 0xFFFFFFFFu;      // the live view (if any) no longer matches the state: re-materialise on demand
     return FS_OK;
 }
 
@@ -716,6 +723,70 @@ fs_status fs_selftest_constdiv(int device, float c, float y, float lo, float hi,
 /* Did the create-time proofs succeed for this handle's constants (2h^3, h^2)?  Bits 0 / 1. */
 int fs_constdiv_status(const fs_sim* s) {
     return s ? (s->div_2h3.ok ? 1 : 0) | (s->div_h2.ok ? 2 : 0) | (s->rcp_ok ? 4 : 0) | (s->sqrt_ok ? 8 : 0) : 0;
+}
+
+/* ------------------------------------------------- renderer hand-off without a host round trip */
+fs_status fs_export_handle(fs_sim* s, int which, fs_mem_handle* out) {
+    if (!s || !out) return fail(FS_ERR_INVALID, "null argument");
+    if (s->slab) return fail(FS_ERR_UNSUPPORTED, "export on a slab handle");
+    if (which != FS_EXPORT_PARTICLES && which != FS_EXPORT_START_INDICES) return fail(FS_ERR_INVALID, "unknown export");
+    FS_HIP(hipSetDevice(s->device));
+    std::memset(out, 0, sizeof *out);
+    void* base = nullptr;
+    if (which == FS_EXPORT_PARTICLES) {
+        if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
+        if (!s->aos_live) {
+            s->aos_live = true;                    // from now on k_force writes the records itself
+            s->aos_tick = 0xFFFFFFFFu;
+        }
+        const fs_particle* dev = nullptr;          // make the view current for the state as it is now
+        fs_status r = fs_particles_device(s, &dev);
+        if (r != FS_OK) return r;
+        base = s->aos.p;
+        out->bytes = (uint64_t)s->n * sizeof(fs_particle);
+    } else {
+        base = s->start_ref.p;
+        out->bytes = (uint64_t)s->start_ref.n * sizeof(uint32_t);
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(out->ipc), "fs_mem_handle.ipc too small");
+    hipIpcMemHandle_t h;
+    FS_HIP(hipIpcGetMemHandle(&h, base));
+    std::memcpy(out->ipc, &h, sizeof h);
+    out->device = s->device;
+    out->dmabuf_fd = -1;
+    // a dma-buf file descriptor of the same range, for consumers outside HIP (Vulkan / wgpu external memory);
+    // optional: older runtimes lack the call, the IPC handle above is the portable path between HIP processes
+    int fd = -1;
+    if (hipMemGetHandleForAddressRange(&fd, base, (size_t)((out->bytes + 4095u) & ~(uint64_t)4095u), hipMemRangeHandleTypeDmaBufFd, 0) == hipSuccess)
+        out->dmabuf_fd = fd;
+    else
+        (void)hipGetLastError();
+    FS_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+fs_status fs_import_open(const fs_mem_handle* h, int device, void** ptr) {
+    if (!h || !ptr) return fail(FS_ERR_INVALID, "null argument");
+    *ptr = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(FS_ERR_DEVICE, "no HIP device");
+    FS_HIP(hipSetDevice(device));
+    hipIpcMemHandle_t ih;
+    std::memcpy(&ih, h->ipc, sizeof ih);
+    FS_HIP(hipIpcOpenMemHandle(ptr, ih, hipIpcMemLazyEnablePeerAccess));
+    return FS_OK;
+}
+
+fs_status fs_import_read(const void* dev_ptr, size_t offset, void* dst, size_t bytes) {
+    if (!dev_ptr || (!dst && bytes)) return fail(FS_ERR_INVALID, "null argument");
+    FS_HIP(hipMemcpy(dst, (const char*)dev_ptr + offset, bytes, hipMemcpyDeviceToHost));
+    return FS_OK;
+}
+
+fs_status fs_import_close(void* ptr) {
+    if (!ptr) return FS_OK;
+    FS_HIP(hipIpcCloseMemHandle(ptr));
+    return FS_OK;
 }
 
 /* ------------------------------------------------------------ slab mode */

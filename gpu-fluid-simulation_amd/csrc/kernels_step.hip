@@ -526,6 +526,8 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
 // amdgpu_waves_per_eu(8, 8): with the chunked sweep inlined next to the mask sweep the allocator would take
 // 83 VGPRs (5 waves/SIMD) and the common path loses 9 %; capped at 64 it spills in the rarely taken
 // branches instead (measured: 0.77 vs 0.86 ms in the bench window, 2.67 vs 2.82 ms in the dense regime).
+struct AosParticle { float2 position, predicted, velocity; float density; uint32_t grid; };   // ParticleInstance, 32 B
+
 #ifndef FS_FORCE_WAVES
 #define FS_FORCE_WAVES 8
 #endif
@@ -536,7 +538,8 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
                                                     const uint32_t* __restrict__ cs,
                                                     const uint32_t* __restrict__ start_ref,
                                                     const u64* __restrict__ pairs, const float2* __restrict__ tex,
-                                                    float2* __restrict__ pos_out, float2* __restrict__ vel_out) {
+                                                    float2* __restrict__ pos_out, float2* __restrict__ vel_out,
+                                                    AosParticle* __restrict__ aos_out) {
     __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
@@ -641,10 +644,16 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
     if (fabsf(p.y) > P.bs_y) { p.y = P.bs_y * sign_f32(p.y); v.y *= -1.0f * P.damping; }
     pos_out[i] = p;
     vel_out[i] = v;
+    if (aos_out) {   // uniform: a renderer hand-off is registered (fs_export_handle) — the 32-byte ParticleInstance the
+                     // reference's fragment shader binds (src/simulation.rs:552-559) is written here, no export pass
+        AosParticle a;
+        a.position = p; a.predicted = me; a.velocity = v; a.density = mrho;
+        a.grid = cy * P.grid_w + cx;      // == the sorted key: same expression as cell_of_point(pred) (single-domain handles only)
+        aos_out[i] = a;
+    }
 }
 
 // --------------------------------------------------------------- AoS <-> SoA
-struct AosParticle { float2 position, predicted, velocity; float density; uint32_t grid; };
 
 __global__ __launch_bounds__(FS_BLOCK) void k_export_aos(uint32_t n, const float2* __restrict__ pos,
                                                          const float2* __restrict__ pred,
@@ -803,14 +812,14 @@ void launch_density(hipStream_t st, const StepParams& P, const float2* pred, con
 
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
-                  float2* pos_out, float2* vel_out) {
+                  float2* pos_out, float2* vel_out, void* aos_out) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
     if (P.fast_math)
         hipLaunchKernelGGL(k_force<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
-                           start_ref, pairs, tex, pos_out, vel_out);
+                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out);
     else
         hipLaunchKernelGGL(k_force<false>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
-                           start_ref, pairs, tex, pos_out, vel_out);
+                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out);
 }
 
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,

@@ -137,6 +137,60 @@ class Transport:
             req.wait()          # nccl: makes the current stream wait; gloo: blocks the host
 
 
+class _DevMsg:
+    """A device message buffer with the two accessors the engine adapter needs."""
+
+    def __init__(self, g, name, nbytes, device_index):
+        self.buf = g.ResizableBuffer(name, np.uint8, nbytes, device=device_index)
+
+    def data_ptr(self):
+        return self.buf.device_ptr
+
+
+class NativeTransport:
+    """The same neighbour exchange through the C ABI's own RCCL binding (fs_comm_init / fs_slab_exchange,
+    csrc/comm.hip): grouped ncclSend/ncclRecv on the simulation's stream, no torch tensor or torch stream on the
+    data path — what a Rust (or any non-Python) host calls.  torch.distributed is used ONCE, to ship rank 0's
+    128-byte RCCL id to the other ranks; any rendezvous would do.  Opt-in: FS_NATIVE_RCCL=1 for bench.py --gpus N."""
+
+    def __init__(self, g, rank, world, message_bytes, device_index, dist=None):
+        self.g, self.rank, self.world = g, rank, world
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+        self.device = ("native", device_index)      # not None: the engine adapter writes the messages in place
+        self.torch_device = None                    # where the (torch) re-balancing all-reduces run; set by the caller
+        self.send_left, self.send_right, self.recv_left, self.recv_right = (
+            _DevMsg(g, k, message_bytes, device_index) for k in ("send_left", "send_right", "recv_left", "recv_right"))
+        lib = g.load_library()
+        idbuf = (C.c_uint8 * 128)()
+        if rank == 0:
+            g._check(lib, lib.fs_comm_unique_id(idbuf))
+        if world > 1:
+            box = [bytes(idbuf)]
+            dist.broadcast_object_list(box, src=0)
+            idbuf = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        self.comm = C.c_void_p()
+        g._check(lib, lib.fs_comm_init(int(device_index), rank, world, idbuf, C.byref(self.comm)))
+        self.lib, self.sim_handle = lib, None
+        import torch
+        import torch.distributed as tdist
+        self.torch, self.dist = torch, tdist        # re-balancing all-reduces stay on torch (tiny, every K steps)
+
+    def bind(self, sim):
+        self.sim_handle = sim._h
+
+    def exchange(self):
+        P = lambda m: C.c_void_p(m.data_ptr())
+        self.g._check(self.lib, self.lib.fs_slab_exchange(
+            self.sim_handle, self.comm, -1 if self.left is None else self.left, -1 if self.right is None else self.right,
+            P(self.send_left), P(self.send_right), P(self.recv_left), P(self.recv_right)))
+
+    def close(self):
+        if self.comm.value:
+            self.lib.fs_comm_destroy(self.comm)
+            self.comm = C.c_void_p()
+
+
 # ----------------------------------------------------------------------------- engines
 class HipSlabEngine:
     """Adapter over the C ABI.  With a CUDA transport the messages are torch CUDA tensors and
@@ -150,6 +204,8 @@ class HipSlabEngine:
                                     recv_capacity, max_cols, device=device_index)
         self.t = transport
         self.cuda = transport.device is not None
+        if hasattr(transport, "bind"):
+            transport.bind(self.sim)
         if not self.cuda:
             mb = self.sim.message_bytes
             self.dev = {k: g.ResizableBuffer(k, np.uint8, mb, device=device_index)
@@ -234,8 +290,9 @@ class SlabDriver:
     def _allreduce(self, arr, op):
         torch, dist = self.t.torch, self.t.dist
         th = torch.from_numpy(arr)
-        if self.t.device is not None:
-            th = th.to(self.t.device)
+        tdev = getattr(self.t, "torch_device", self.t.device)
+        if tdev is not None:
+            th = th.to(tdev)
         dist.all_reduce(th, op=op)
         return th.cpu().numpy()
 
@@ -313,6 +370,27 @@ def lattice_histogram(g, settings, offset):
     return np.bincount(cols, minlength=gw)[:gw].astype(np.int64), gw
 
 
+def scaling_base(g, settings, off, tick, gh, gw, device_index, warmup, steps):
+    """ms/step of the slab engine as ONE rank over the whole domain (no neighbours, no exchange), same window."""
+    import ctypes as C
+    n = settings.particle_count
+    cap, recv = slab_capacities(n, 1, gh)
+    sim = g.SlabSimulation(settings, 0, gw, False, False, cap, recv, gw, device=device_index)
+    sim.upload_owned(g.reference_lattice(settings, off))
+    for _ in range(warmup):
+        sim.pack(tick, None, None); sim.step(None, None)
+    sim.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.pack(tick, None, None); sim.step(None, None)
+    sim.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    ok = sim.counters()
+    sim.close()
+    return {"ms_per_step": round(ms, 4), "value": round(n / (ms * 1e-3) / 1e6, 2), "unit": "M particle-steps/s",
+            "n_gpus": 1, "engine": "slab engine, 1 rank, counting sort", "violations": ok["lost"] + ok["overflow"] + ok["far_halo"]}
+
+
 # ----------------------------------------------------------------------------- bench entry
 def bench_main(args, rank, local_rank, world):
     """bench.py --gpus N (N > 1): strong scaling of the 16M dam break over N slabs."""
@@ -339,7 +417,12 @@ def bench_main(args, rank, local_rank, world):
     bounds = trim_outer_edges(bounds, hist, default_trim_margin() if rebalance_every > 0 else 0)
     msg_bytes = HEADER_BYTES + RECORD_BYTES * recv
     dev = torch.device("cuda", local_rank) if backend == "nccl" else None
-    tr = Transport(rank, world, msg_bytes, device=dev)
+    native = bool(os.environ.get("FS_NATIVE_RCCL")) and backend == "nccl"
+    if native:      # the C ABI's own RCCL binding (fs_slab_exchange): what a non-Python host would run
+        tr = NativeTransport(g, rank, world, msg_bytes, local_rank, dist)
+        tr.torch_device = dev
+    else:
+        tr = Transport(rank, world, msg_bytes, device=dev)
     eng = HipSlabEngine(g, settings, bounds, rank, world, cap, recv, max_cols, local_rank, tr)
     assert eng.message_bytes == msg_bytes
     eng.sim.upload_owned(initial_owned(g, settings, off, bounds, rank))
@@ -368,6 +451,9 @@ def bench_main(args, rank, local_rank, world):
     nlive = torch.tensor([int(eng.owned_particles().shape[0])], dtype=torch.int64,
                          device=dev if dev is not None else "cpu")
     dist.all_reduce(nlive)
+    base = None
+    if rank == 0 and not os.environ.get("FS_NO_SCALING_BASE"):
+        base = scaling_base(g, settings, off, tick, gh, gw, local_rank, args.warmup, args.steps)
     if rank == 0:
         ms_per_step = float(tmax.item()) * 1e3 / args.steps
         value = n / (ms_per_step * 1e-3) / 1e6
@@ -378,7 +464,7 @@ def bench_main(args, rank, local_rank, world):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "particles": n, "scene": "SURVEY.md §8d dam_break_2d",
                        "sort": "counting (slab default: per-rank sorts are tolerance-parity by construction)",
-                       "parallelism": f"{world} column slabs, RCCL p2p halo ({backend})",
+                       "parallelism": f"{world} column slabs, RCCL p2p halo ({backend}" + (", C-ABI fs_slab_exchange)" if native else ", torch.distributed)"),
                        "slab_columns": [drv.bounds[k + 1] - drv.bounds[k] for k in range(world)],
                        "outer_trim_margin": drv.trim_margin,
                        "message_bytes": msg_bytes},
@@ -386,6 +472,10 @@ def bench_main(args, rank, local_rank, world):
                          "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(agg / (HBM_PEAK_GBS * world), 4),
                          "traffic": None},
             "checks": {"particles_conserved": int(nlive.item()) == n, "protocol_violations": int(bad.item())},
+            # like-for-like base of the scaling curve: N = 1 of bench.py runs the PLAIN engine with the reference
+            # network; this is the SAME slab engine (counting sort, fixed-capacity slots, pack/unpack) as ONE rank
+            "scaling_base": base,
+            "multi_gpu_note": "8-GPU timing is produced by the driver's SCALE run only; this builder's boxes have one GPU",
         }
         print(json.dumps(out), flush=True)
     dist.barrier()

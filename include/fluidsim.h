@@ -36,7 +36,7 @@ typedef enum fs_status {
     FS_ERR_DEVICE = 2,       /* HIP runtime error (message in fs_last_error) */
     FS_ERR_OOM = 3,          /* device or host allocation failed */
     FS_ERR_UNSUPPORTED = 4,  /* option combination not built */
-    FS_ERR_COMM = 5          /* RCCL error */
+    FS_ERR_COMM = 5          /* RCCL error, or librccl could not be loaded (fs_comm_*, fs_slab_exchange) */
 } fs_status;
 
 /* ------------------------------------------------------------------- PODs */
@@ -181,6 +181,29 @@ fs_status fs_get_uniform(const fs_sim* sim, fs_uniform* out);
 /* force_field_texture() (src/simulation.rs:562-564) + queue.write_buffer (src/renderer.rs:497-502). */
 fs_status fs_upload_force_field(fs_sim* sim, const fs_vec2* field, uint32_t w, uint32_t h);
 
+/* ---- hand-off without a host round trip --------------------------------------------
+ * The reference's renderer binds the simulation's particle and start_indices buffers directly
+ * (simulation_bg: src/simulation.rs:552-559, used at src/renderer.rs:457-458; fluid_shader.wgsl:38-75).
+ * fs_export_handle gives a consumer in ANOTHER process (or another API) the same thing: an interprocess
+ * handle of the device allocation holding the cell-sorted 32-byte records / the start_indices table.
+ * Registering the particle export switches the engine to a LIVE AoS view: from the next fs_step on the force pass
+ * writes the ParticleInstance records itself (no export pass, no copy); the consumer reads them after fs_sync
+ * (or after its own wait on the step).  `ipc` is a hipIpcMemHandle_t (HIP consumers: fs_import_open);
+ * `dmabuf_fd` is a dma-buf file descriptor of the same range for external-memory import by Vulkan / wgpu
+ * (-1 when the runtime cannot export one); the caller owns and closes it. */
+enum { FS_EXPORT_PARTICLES = 0, FS_EXPORT_START_INDICES = 1 };
+typedef struct fs_mem_handle {
+    uint8_t ipc[64];
+    uint64_t bytes;       /* size of the exported range: particle_count * 32, or grid_w * grid_h * 4 */
+    int32_t device;       /* HIP ordinal the allocation lives on */
+    int32_t dmabuf_fd;
+} fs_mem_handle;
+fs_status fs_export_handle(fs_sim* sim, int which, fs_mem_handle* out);
+/* Consumer side (any process with a HIP device): map an exported range, read from it, unmap. */
+fs_status fs_import_open(const fs_mem_handle* handle, int device, void** dev_ptr);
+fs_status fs_import_read(const void* dev_ptr, size_t offset, void* dst, size_t bytes);   /* blocking copy to host */
+fs_status fs_import_close(void* dev_ptr);
+
 /* Host copies (checkpoint / tests).  Blocking.  n = number of records. */
 fs_status fs_download_particles(fs_sim* sim, fs_particle* dst, size_t n);
 fs_status fs_upload_particles(fs_sim* sim, const fs_particle* src, size_t n);
@@ -273,6 +296,24 @@ fs_status fs_slab_download(fs_sim* sim, fs_particle* dst, uint8_t* owned, size_t
 fs_status fs_slab_max_speed(fs_sim* sim, float* out);
 /* Per-global-column particle counts of the owned columns (others untouched); blocking. */
 fs_status fs_slab_column_histogram(fs_sim* sim, uint32_t* hist, size_t grid_w_global);
+
+/* ---- native RCCL transport (csrc/comm.hip): one process per GPU, any host language --------------------------
+ * fs_comm_unique_id on rank 0 -> ship the 128 bytes to every rank -> fs_comm_init everywhere; then per step
+ * fs_slab_pack -> fs_slab_exchange -> fs_slab_step.  The exchange is one grouped ncclSend/ncclRecv set on the
+ * simulation's stream (left_rank / right_rank < 0 = no neighbour on that side); with left_rank == right_rank ==
+ * own rank it is a self-exchange (recv_right receives send_right, recv_left receives send_left).  RCCL failures
+ * return FS_ERR_COMM with the RCCL message in fs_last_error().  fs_comm_allreduce (in place, on the simulation's
+ * stream) serves the re-balancing histogram / violation counters. */
+#define FS_COMM_ID_BYTES 128
+typedef struct fs_comm fs_comm;
+enum { FS_COMM_U32 = 0, FS_COMM_U64 = 1, FS_COMM_F32 = 2 };
+enum { FS_COMM_SUM = 0, FS_COMM_MAX = 1 };
+fs_status fs_comm_unique_id(uint8_t id[FS_COMM_ID_BYTES]);
+fs_status fs_comm_init(int device, int rank, int world, const uint8_t id[FS_COMM_ID_BYTES], fs_comm** out);
+void fs_comm_destroy(fs_comm* comm);
+fs_status fs_slab_exchange(fs_sim* sim, fs_comm* comm, int left_rank, int right_rank, const void* send_left,
+                           const void* send_right, void* recv_left, void* recv_right);
+fs_status fs_comm_allreduce(fs_sim* sim, fs_comm* comm, void* device_buf, size_t count, int dtype, int op);
 
 /* ------------------------------------------------------------ 3D extension */
 /* NOT in the reference (2D only).  Build-defined per SURVEY.md Appendix B.3: same pass

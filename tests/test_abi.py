@@ -121,3 +121,15 @@ def test_header_is_plain_c(fs, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert f"abi 1 symbols {len(names)}" in out.stdout
+
+
+def test_comm_failure_is_fs_err_comm(fs, tmp_path):
+    """RCCL problems surface as FS_ERR_COMM through the ABI (never an abort): here librccl itself cannot be loaded."""
+    import subprocess, sys
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r); import gpu_fluid_simulation_amd as g; lib = g.load_library(); "
+            "b = (C.c_uint8 * 128)(); rc = lib.fs_comm_unique_id(b); print(rc, lib.fs_last_error().decode())" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, FS_RCCL_LIB=str(tmp_path / "no_such_librccl.so")))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.startswith("5 "), out.stdout          # FS_ERR_COMM
+    assert "librccl" in out.stdout

@@ -354,3 +354,48 @@ def test_nccl_single_rank_smoke(fs, tmp_path):
                          timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "nccl smoke ok" in out.stdout
+
+
+NATIVE_SELF = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import gpu_fluid_simulation_amd as g          # no torch in this process: the C ABI alone drives RCCL
+lib = g.load_library()
+st, off, tick = g.dam_break_2d(16384)
+sim = g.SlabSimulation(st, 10, 40, False, False, 16384 + 2 * 2048, 2048, 66, device=0)
+nb = sim.message_bytes
+bufs = {k: g.ResizableBuffer(k, np.uint8, nb) for k in ("sl", "sr", "rl", "rr")}
+rng = np.random.default_rng(3)
+pat = {k: rng.integers(0, 256, nb, dtype=np.uint8) for k in ("sl", "sr")}
+bufs["sl"].write(0, pat["sl"]); bufs["sr"].write(0, pat["sr"])
+idb = (C.c_uint8 * 128)()
+g._check(lib, lib.fs_comm_unique_id(idb))
+comm = C.c_void_p()
+g._check(lib, lib.fs_comm_init(0, 0, 1, idb, C.byref(comm)))
+P = lambda b: C.c_void_p(b.device_ptr)
+for _ in range(3):
+    g._check(lib, lib.fs_slab_exchange(sim._h, comm, 0, 0, P(bufs["sl"]), P(bufs["sr"]), P(bufs["rl"]), P(bufs["rr"])))
+sim.sync()
+assert np.array_equal(bufs["rr"].read(), pat["sr"]) and np.array_equal(bufs["rl"].read(), pat["sl"])
+# in-place all-reduce on the simulation's stream (single rank: identity) — the histogram path of a native host
+h = g.ResizableBuffer("hist", np.uint32, 64)
+h.write(0, np.arange(64, dtype=np.uint32))
+g._check(lib, lib.fs_comm_allreduce(sim._h, comm, C.c_void_p(h.device_ptr), 64, 0, 0))
+sim.sync()
+assert np.array_equal(h.read(), np.arange(64, dtype=np.uint32))
+# no neighbours: nothing is issued, nothing fails
+g._check(lib, lib.fs_slab_exchange(sim._h, comm, -1, -1, None, None, None, None))
+lib.fs_comm_destroy(comm)
+print("native rccl self-exchange ok", nb)
+'''
+
+
+def test_native_rccl_self_exchange_through_the_c_abi(fs, tmp_path):
+    """fs_comm_* / fs_slab_exchange (csrc/comm.hip): grouped ncclSend/ncclRecv on the simulation's stream, driven
+    from a process that never imports torch — a single-rank communicator exchanging both messages with itself."""
+    script = tmp_path / "native_self.py"
+    script.write_text(NATIVE_SELF)
+    out = subprocess.run([sys.executable, str(script), ROOT], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "native rccl self-exchange ok" in out.stdout
