@@ -43,7 +43,23 @@ extern "C" {
     fn fs_upload_force_field(sim: *mut fs_sim, field: *const Vec2, w: u32, h: u32) -> c_int;
     fn fs_download_particles(sim: *mut fs_sim, dst: *mut ParticleInstance, n: usize) -> c_int;
     fn fs_last_error() -> *const c_char;
+    // hand-off without a host round trip (include/fluidsim.h: fs_export_handle)
+    fn fs_export_handle(sim: *mut fs_sim, which: c_int, out: *mut MemHandle) -> c_int;
+    // native RCCL transport for a multi-GPU host (include/fluidsim.h: fs_comm_*, fs_slab_exchange)
+    fn fs_comm_unique_id(id: *mut u8) -> c_int;
+    fn fs_comm_init(device: c_int, rank: c_int, world: c_int, id: *const u8, out: *mut *mut c_void) -> c_int;
+    fn fs_comm_destroy(comm: *mut c_void);
+    fn fs_slab_exchange(sim: *mut fs_sim, comm: *mut c_void, left_rank: c_int, right_rank: c_int,
+                        send_left: *const c_void, send_right: *const c_void,
+                        recv_left: *mut c_void, recv_right: *mut c_void) -> c_int;
 }
+
+/// fs_mem_handle: interprocess / external-memory handle of a device buffer of the simulation (80 bytes).
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct MemHandle { pub ipc: [u8; 64], pub bytes: u64, pub device: i32, pub dmabuf_fd: i32 }
+const _: () = assert!(std::mem::size_of::<MemHandle>() == 80);
+pub const EXPORT_PARTICLES: c_int = 0;
+pub const EXPORT_START_INDICES: c_int = 1;
 
 fn check(status: c_int) {
     if status != 0 {
@@ -86,6 +102,29 @@ impl FluidSimulation {
         let mut v = vec![ParticleInstance::default(); self.settings.particle_count as usize];
         check(unsafe { fs_download_particles(self.raw, v.as_mut_ptr(), v.len()) }); v
     }
+    /// Zero-copy hand-off: export the particle (or start_indices) allocation.  `dmabuf_fd` imports into Vulkan / wgpu
+    /// as external memory (the buffers `simulation_bg` binds, src/simulation.rs:552-559); after this call the force
+    /// pass writes the 32-byte records itself, so each frame costs no export pass and no PCIe copy.
+    pub fn export(&mut self, which: c_int) -> MemHandle {
+        let mut h = MemHandle { ipc: [0; 64], bytes: 0, device: 0, dmabuf_fd: -1 };
+        check(unsafe { fs_export_handle(self.raw, which, &mut h) }); h
+    }
     pub fn raw(&mut self) -> *mut c_void { self.raw as *mut c_void }
 }
+
+/// One RCCL communicator per process / GPU (multi-GPU slab runs: fs_slab_pack -> Comm::exchange -> fs_slab_step).
+pub struct Comm { raw: *mut c_void }
+impl Comm {
+    pub fn unique_id() -> [u8; 128] { let mut id = [0u8; 128]; check(unsafe { fs_comm_unique_id(id.as_mut_ptr()) }); id }
+    pub fn init(hip_device: i32, rank: i32, world: i32, id: &[u8; 128]) -> Self {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { fs_comm_init(hip_device, rank, world, id.as_ptr(), &mut raw) }); Self { raw }
+    }
+    /// Grouped ncclSend/ncclRecv of the two fixed-size slab messages on the simulation's own stream.
+    pub unsafe fn exchange(&self, sim: *mut c_void, left: i32, right: i32, send_left: *const c_void,
+                           send_right: *const c_void, recv_left: *mut c_void, recv_right: *mut c_void) {
+        check(fs_slab_exchange(sim as *mut fs_sim, self.raw, left, right, send_left, send_right, recv_left, recv_right));
+    }
+}
+impl Drop for Comm { fn drop(&mut self) { unsafe { fs_comm_destroy(self.raw) } } }
 impl Drop for FluidSimulation { fn drop(&mut self) { unsafe { fs_destroy(self.raw) } } }
