@@ -17,6 +17,7 @@ import numpy as np
 from . import _abi
 from ._abi import (  # noqa: F401
     FS_MATH_IEEE,
+    FS_MATH_TOLERANCE,
     FS_MATH_WGSL_ULP,
     FS_SORT_BITONIC,
     FS_SORT_COUNTING,

@@ -163,6 +163,7 @@ FS_SORT_BITONIC = 0
 FS_SORT_COUNTING = 1
 FS_MATH_IEEE = 0
 FS_MATH_WGSL_ULP = 1
+FS_MATH_TOLERANCE = 2
 
 PASS_NAMES = ("predict_key", "sort", "reorder", "density", "force")
 FS_EXPORT_PARTICLES = 0

@@ -117,6 +117,7 @@ struct fs_sim {
     DevArray<uint32_t> cs;          // dense cell-start table, ncell+1
     DevArray<uint32_t> start_ref;   // reference start_indices (persistent, never cleared)
     DevArray<float2> tex;           // force field
+    bool tex_zero = true;           // the host knows every entry is +-0 (zero-initialised, or an all-zero upload)
     DevArray<unsigned char> work;   // gap worklist
     DevArray<uint32_t> counter;
     uint32_t work_cap = 0;
@@ -242,8 +243,9 @@ fsd::StepParams make_params(const fs_sim& s) {
     P.tex_w = u.texture_size.x; P.tex_h = u.texture_size.y;
     P.tex_w_u = s.settings.texture_size.x;   // u32(u.texture_size.x), compute.wgsl:129
     P.tex_len = (uint32_t)s.tex.n;
+    P.tex_zero = s.tex_zero ? 1 : 0;
     P.ref_quirks = s.opts.ref_quirks;
-    P.fast_math = s.opts.math_mode == FS_MATH_WGSL_ULP ? 1 : 0;
+    P.fast_math = s.opts.math_mode == FS_MATH_WGSL_ULP ? 1 : s.opts.math_mode == FS_MATH_TOLERANCE ? 2 : 0;
     P.div_2h3 = s.div_2h3;
     P.div_h2 = s.div_h2;
     // div_by_rcp's guards assume dst <= ~h <= 2^19 (fs_device.h); FS_NO_SHAREDIV=1 keeps every `/` a true division
@@ -371,7 +373,7 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p, s->aos_live ? (void*)s->aos.p : nullptr);
+                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->aos_live ? (void*)s->aos.p : nullptr);
     if (s->aos_live) s->aos_tick = s->tick;
     if (prof) {
         FS_HIP(hipEventRecord(ev[5], st));
@@ -410,7 +412,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     if (!settings_valid(*settings, &why)) return fail(FS_ERR_INVALID, why);
     if (opts->sort_mode != FS_SORT_BITONIC && opts->sort_mode != FS_SORT_COUNTING)
         return fail(FS_ERR_INVALID, "unknown sort_mode");
-    if (opts->math_mode != FS_MATH_IEEE && opts->math_mode != FS_MATH_WGSL_ULP)
+    if (opts->math_mode != FS_MATH_IEEE && opts->math_mode != FS_MATH_WGSL_ULP && opts->math_mode != FS_MATH_TOLERANCE)
         return fail(FS_ERR_INVALID, "unknown math_mode");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -542,7 +544,10 @@ fs_status fs_upload_force_field(fs_sim* s, const fs_vec2* field, uint32_t w, uin
         return fail(FS_ERR_INVALID, "force field dimensions differ from settings.texture_size");
     FS_HIP(hipSetDevice(s->device));
     FS_HIP(hipMemcpyAsync(s->tex.p, field, (size_t)w * h * sizeof(fs_vec2), hipMemcpyHostToDevice, s->stream));
+    bool zero = true;               // while the copy runs: does the field push anything at all? (`!= 0`: -0 is zero, NaN is not)
+    for (size_t k = 0, m = (size_t)w * h; k < m && zero; ++k) zero = !(field[k].x != 0.0f) && !(field[k].y != 0.0f);
     FS_HIP(hipStreamSynchronize(s->stream));
+    s->tex_zero = zero;
     return FS_OK;
 }
 
@@ -638,6 +643,7 @@ fs_status fs_generate_force_field(fs_sim* s, int device, const uint8_t* image, u
     if (e == hipSuccess) e = hipMalloc((void**)&dnear, npix * sizeof(uint32_t));
     if (e == hipSuccess && !s) e = hipMalloc((void**)&dfield, npix * sizeof(float2));
     float2* out = s ? s->tex.p : dfield;
+    if (s) s->tex_zero = false;     // produced on the device: contents unknown to the host
     if (e == hipSuccess) e = hipMemcpyAsync(dimg, image, npix, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) { fsd::launch_gradient_field(st, dimg, w, h, ddist, dnear, out); e = hipGetLastError(); }
     if (e == hipSuccess && field_host) e = hipMemcpyAsync(field_host, out, npix * sizeof(float2), hipMemcpyDeviceToHost, st);
@@ -959,7 +965,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p);
     if (ev) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p);
+                      s->tex.p, s->pos.p, s->vel.p, s->rho.p);
     if (ev) { FS_HIP(hipEventRecord(ev[5], st)); s->prof_pending += 1; }
     FS_HIP(hipGetLastError());
     s->slab_packed = false;

@@ -35,6 +35,7 @@ struct StepParams {
     uint32_t frame_time;
     float tex_w, tex_h;
     uint32_t tex_w_u, tex_len;
+    int32_t tex_zero;          // host knows the force field is all zeros: the lookup of compute.wgsl:127-140 is skipped
     int32_t ref_quirks;
     int32_t fast_math;         // FS_MATH_WGSL_ULP: native rcp/sqrt in the force pass (not bit-exact)
     ConstDiv div_2h3, div_h2;  // the two constant denominators of funcs.wgsl:119 (2h^3, h^2)

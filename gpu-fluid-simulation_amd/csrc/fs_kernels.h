@@ -19,7 +19,8 @@ void launch_density(hipStream_t st, const StepParams& P, const float2* pred, con
                     float2* rho2 /* {rho, +-RN(1/rho)}: the sign is the particle's safe-operand classification */);
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
-                  float2* pos_out, float2* vel_out, void* aos_out = nullptr /* 32-B ParticleInstance records, or none */);
+                  float2* pos_out, float2* vel_out, const float* rho_arr,
+                  void* aos_out = nullptr /* 32-B ParticleInstance records, or none */);
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
                        const float* rho, const uint32_t* key, void* out);
 void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, float2* pred, float2* vel, float* rho,

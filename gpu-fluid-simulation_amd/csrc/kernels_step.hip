@@ -119,6 +119,12 @@ __device__ __forceinline__ bool row_range(const StepParams& P, const uint32_t* _
 #define NB_TILE 640          // staged candidates per sweep row
 
 // -------------------------------------------------------------------- density
+__device__ __forceinline__ float density_cube_tol(float h2, float2 me, float2 q, float acc) {
+    const float dx = q.x - me.x, dy = q.y - me.y;
+    const float t = fmaxf(h2 - __builtin_fmaf(dx, dx, dy * dy), 0.0f);      // NaN candidate: contributes nothing
+    return __builtin_fmaf(t * t, t, acc);
+}
+
 __device__ __forceinline__ float density_term(const StepParams& P, float h2, float2 me, float2 q) {
     const float dx = q.x - me.x, dy = q.y - me.y;
     const float r2 = dx * dx + dy * dy;
@@ -130,6 +136,9 @@ __device__ __forceinline__ float density_term(const StepParams& P, float h2, flo
     return P.mass * kern * 1.0f;                        // funcs.wgsl:192
 }
 
+// TOL (fs_options.math_mode = FS_MATH_TOLERANCE): r2 by one fma, max(h2 - r2, 0) instead of the compare/select, the
+// constant factor mass * 4/(pi h^8) applied once to the sum; stores {pressure_i, 1/rho_i} for the merged force terms.
+template <bool TOL>
 __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2* __restrict__ pred,
                                                       const uint32_t* __restrict__ cs,
                                                       const uint32_t* __restrict__ start_ref,
@@ -171,6 +180,15 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
             const bool any = R.lo[r] < R.hi[r];
             const uint32_t hi = any ? R.hi[r] - blo[r] : 0u;
             uint32_t k = any ? R.lo[r] - blo[r] : 0u;
+            if (TOL) {
+                for (; k + 4u <= hi; k += 4u) {
+                    const float2 q0 = sp[k], q1 = sp[k + 1u], q2 = sp[k + 2u], q3 = sp[k + 3u];
+                    rho = density_cube_tol(h2, me, q0, rho); rho = density_cube_tol(h2, me, q1, rho);
+                    rho = density_cube_tol(h2, me, q2, rho); rho = density_cube_tol(h2, me, q3, rho);
+                }
+                for (; k < hi; ++k) rho = density_cube_tol(h2, me, sp[k], rho);
+                continue;
+            }
             for (; k + 4u <= hi; k += 4u) {
                 const float t0 = density_term(P, h2, me, sp[k]);
                 const float t1 = density_term(P, h2, me, sp[k + 1u]);
@@ -183,9 +201,19 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
     } else {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-            for (uint32_t k = R.lo[r]; k < R.hi[r]; ++k) rho += density_term(P, h2, me, pred[k]);
+            for (uint32_t k = R.lo[r]; k < R.hi[r]; ++k) {
+                if (TOL) rho = density_cube_tol(h2, me, pred[k], rho);
+                else rho += density_term(P, h2, me, pred[k]);
+            }
     }
     if (!live) return;
+    if (TOL) {
+        rho = rho * (P.mass * P.poly6_norm);                    // sum of (h2 - r2)^3 -> density
+        rho = fmaxf(fmaxf(rho, 1.19209290e-07f), 0.1f);
+        rho_out[i] = rho;
+        rho2_out[i] = make_float2(P.pressure_k * (rho - P.rest_density), __fdiv_rn(1.0f, rho));
+        return;
+    }
     rho = fmaxf(rho, 1.19209290e-07f);                          // funcs.wgsl:202
     rho = fmaxf(rho, 0.1f);                                     // compute.wgsl:70
     rho_out[i] = rho;
@@ -275,6 +303,50 @@ __device__ __forceinline__ ForceTerms force_terms(const StepParams& P, const flo
     return T;
 }
 
+// ---- tolerance mode (MODE 2, fs_options.math_mode = FS_MATH_TOLERANCE) ------------------------------------------
+// The pressure and viscosity terms of one in-radius neighbour merged algebraically (compute.wgsl:207-223, :283-288,
+// funcs.wgsl:101-123): one v_rsq_f32, fused multiply-adds, pressure_j and 1/rho_j precomputed per particle by
+// k_density<true> — 24 issue slots per pair instead of ~85.  Within rtol 1e-5 / atol 1e-4*h of the IEEE oracle per
+// step (tests/test_parity_gpu.py::test_tolerance_mode_*); cell keys and start_indices stay bit-exact (they come
+// from the sort and the reorder pass, which this mode does not touch).  Coincident particles (r == 0) keep the
+// reference's xorshift direction.
+struct TolConsts { float cP, c3, c2, hh; };
+__device__ __forceinline__ TolConsts tol_consts(const StepParams& P) {
+    TolConsts C;
+    const float h = P.h;
+    C.cP = -0.5f * P.spiky;                       // kern * 0.5 = -(h - dst) * spiky * 0.5
+    C.c3 = -1.0f / (2.0f * h * h * h);
+    C.c2 = 1.0f / (h * h);
+    C.hh = 0.5f * h;
+    return C;
+}
+__device__ __forceinline__ void force_accum_tol(const StepParams& P, const TolConsts& C, const float2 me, const float2 mv,
+                                                float pressure, const float2 q, const float2 nv,
+                                                const float2 nd /* {pressure_j, 1/rho_j} */, ForceAcc& A) {
+    const float ox = q.x - me.x, oy = q.y - me.y;
+    const float r2 = __builtin_fmaf(ox, ox, oy * oy);
+    float dirx = ox, diry = oy, inv, dst;
+    if (r2 == 0.0f) {                                                   // compute.wgsl:211-212 (rare)
+        const float rx = rand_f32(&A.seed), ry = rand_f32(&A.seed);
+        const float il = __builtin_amdgcn_rsqf(__builtin_fmaf(rx, rx, ry * ry));
+        dirx = rx * il; diry = ry * il;
+        dst = 0.0f; inv = 1.0f;                                         // dir is already normalised
+    } else {
+        inv = __builtin_amdgcn_rsqf(r2);
+        dst = r2 * inv;
+    }
+    const float w = fmaxf(P.h - dst, 0.0f);                             // dst <= h for every admitted candidate
+    const float coefP = (w * C.cP) * (pressure + nd.x) * nd.y * inv;
+    float u = __builtin_fmaf(C.c3, dst, C.c2);
+    u = __builtin_fmaf(u, r2, -1.0f);
+    u = r2 == 0.0f ? 1.0f : __builtin_fmaf(C.hh, inv, u);               // funcs.wgsl:116: r == 0 -> the bare constant
+    const float kvv = u * (P.visc_k * nd.y);
+    A.fpx = __builtin_fmaf(dirx, coefP, A.fpx);
+    A.fpy = __builtin_fmaf(diry, coefP, A.fpy);
+    A.fvx = __builtin_fmaf(nv.x - mv.x, kvv, A.fvx);
+    A.fvy = __builtin_fmaf(nv.y - mv.y, kvv, A.fvy);
+}
+
 // The exact body behind a real call (FS_SLOW_NOINLINE): the hot loops then carry only the call's argument set-up
 // instead of the whole true-division body in their register allocation.
 #ifdef FS_SLOW_NOINLINE
@@ -349,13 +421,15 @@ __device__ __forceinline__ void shift_in_not_greater(uint32_t& mask, float r2, f
 // visits its neighbours in the reference order; lanes idle while others finish a chunk (dense regions
 // only — the common case never comes here).  STAGED: candidates from the LDS tile, else from global
 // memory (the pred array is allocated with FS_PRED_SLACK elements of slack for the read-ahead).
-template <bool STAGED, bool FAST>
+template <bool STAGED, int MODE>
 __device__ __forceinline__ void force_sweep_chunks(const StepParams& P, const RowRanges& R, const uint32_t* blo,
                                                    uint32_t ii, const float2 me, const float2 mv, float pressure,
                                                    const float2* __restrict__ pred, const float2* __restrict__ vel_s,
                                                    const float2* __restrict__ rho2, const float2* s_flat, bool me_ok,
                                                    ForceAcc& A) {
     const float lim = P.sqr_radius;
+    constexpr bool FAST = MODE == 1;
+    const TolConsts TC = tol_consts(P);
     const wave_mask me_okm = wm(me_ok);      // the lane's own "safe operand" classification (all lanes active here)
     // plain registers: as arrays the row selects below become dynamic indexing, which the compiler
     // serves from scratch / promoted LDS
@@ -409,7 +483,9 @@ __device__ __forceinline__ void force_sweep_chunks(const StepParams& P, const Ro
                 const bool cur_valid = have;
                 const float2 q0 = qn, v0 = vn, d0 = dn;
                 FS_FETCH_NEXT1();
-                if (cur_valid) {
+                if (cur_valid && MODE == 2) {
+                    force_accum_tol(P, TC, me, mv, pressure, q0, v0, d0, A);
+                } else if (cur_valid) {
                     ForceTerms T0;
                     if (FAST) {
                         T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
@@ -441,13 +517,15 @@ __device__ __forceinline__ void force_sweep_chunks(const StepParams& P, const Ro
 //           own range afterwards, and the middle row clears the lane's own bit (`k != i`, :195).
 //   heavy — every lane walks its set bits, row 0, 1, 2, ascending = the reference visiting order, so
 //           the sums keep their association; all lanes stay busy until the longest list is done.
-template <bool FAST>
+template <int MODE>
 __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const RowRanges& R, const uint32_t* blo,
                                                   uint32_t ii, const float2 me, const float2 mv, float pressure,
                                                   const float2* __restrict__ vel_s, const float2* __restrict__ rho2,
                                                   const float2* s_flat /* [3][NBF_ROW] */, bool me_ok, ForceAcc& A) {
     uint32_t m[3], la[3];                    // masks (bit 31-t <=> candidate lo+t), flat LDS index of lo
     const float lim = P.sqr_radius;
+    constexpr bool FAST = MODE == 1;
+    const TolConsts TC = tol_consts(P);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const uint32_t len = R.hi[r] - R.lo[r];                           // <= 32 (caller)
@@ -502,7 +580,9 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
         const bool cur_valid = have;
         const float2 q0 = qn, v0 = vn, d0 = dn;
         FS_FETCH_NEXT();
-        if (cur_valid) {
+        if (cur_valid && MODE == 2) {
+            force_accum_tol(P, TC, me, mv, pressure, q0, v0, d0, A);
+        } else if (cur_valid) {
             ForceTerms T0;
             if (FAST) {
                 T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
@@ -531,7 +611,7 @@ struct AosParticle { float2 position, predicted, velocity; float density; uint32
 #ifndef FS_FORCE_WAVES
 #define FS_FORCE_WAVES 8
 #endif
-template <bool FAST>
+template <int MODE>
 __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FORCE_WAVES, FS_FORCE_WAVES))) void k_force(StepParams P, const float2* __restrict__ pos_s,
                                                     const float2* __restrict__ vel_s,
                                                     const float2* __restrict__ pred, const float2* __restrict__ rho2,
@@ -539,7 +619,7 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
                                                     const uint32_t* __restrict__ start_ref,
                                                     const u64* __restrict__ pairs, const float2* __restrict__ tex,
                                                     float2* __restrict__ pos_out, float2* __restrict__ vel_out,
-                                                    AosParticle* __restrict__ aos_out) {
+                                                    AosParticle* __restrict__ aos_out, const float* __restrict__ rho_arr) {
     __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
@@ -552,10 +632,10 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
     const float2 me = pred[ii];
     const float2 mv = vel_s[ii];
-    const float2 mrec = rho2[ii];
-    const float mrho = mrec.x;
+    const float2 mrec = rho2[ii];                   // {rho, +-1/rho}; MODE 2: {pressure, 1/rho}
+    const float mrho = MODE == 2 ? 0.0f : mrec.x;
     const bool me_ok = mrec.y > 0.0f;               // this particle's "safe operand" classification (fs_device.h)
-    const float pressure = P.pressure_k * (mrho - P.rest_density);      // funcs.wgsl:152-154
+    const float pressure = MODE == 2 ? mrec.x : P.pressure_k * (mrho - P.rest_density);      // funcs.wgsl:152-154
     ForceAcc A;
     A.fpx = A.fpy = A.fvx = A.fvy = 0.0f;
     A.seed = ii * 12u + P.frame_time * 69u;                             // compute.wgsl:161
@@ -583,11 +663,11 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
         __syncthreads();
         const bool long_row = R.hi[0] - R.lo[0] > 32u || R.hi[1] - R.lo[1] > 32u || R.hi[2] - R.lo[2] > 32u;
         if (!__any(long_row))
-            force_sweep_masks<FAST>(P, R, blo, ii, me, mv, pressure, vel_s, rho2, &s_pred[0][0], me_ok, A);
+            force_sweep_masks<MODE>(P, R, blo, ii, me, mv, pressure, vel_s, rho2, &s_pred[0][0], me_ok, A);
         else
-            force_sweep_chunks<true, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], me_ok, A);
+            force_sweep_chunks<true, MODE>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], me_ok, A);
     } else {
-        force_sweep_chunks<false, FAST>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], me_ok, A);
+        force_sweep_chunks<false, MODE>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], me_ok, A);
     }
     if (!live) return;
     const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
@@ -597,8 +677,13 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
     float2 v = mv;
     float2 p = pos_s[i];
     const float ax = A.fpx + fvx, ay = A.fpy + fvy;
-    v.x += __fdiv_rn(ax, mrho) * P.dt;
-    v.y += __fdiv_rn(ay, mrho) * P.dt;
+    if (MODE == 2) {
+        v.x = __builtin_fmaf(ax * mrec.y, P.dt, v.x);
+        v.y = __builtin_fmaf(ay * mrec.y, P.dt, v.y);
+    } else {
+        v.x += __fdiv_rn(ax, mrho) * P.dt;
+        v.y += __fdiv_rn(ay, mrho) * P.dt;
+    }
     v.x += P.gx * P.dt;
     v.y += P.gy * P.dt;
     if (P.mouse_state != 0) {
@@ -613,21 +698,28 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
         }
     }
     if (!(v.x == v.x && v.y == v.y)) { v.x = 0.0f; v.y = 0.0f; }
-    const float speed = sqrt_rn(v.x * v.x + v.y * v.y);
-    if (speed > 500.0f) {
-        v.x = __fdiv_rn(v.x, speed) * 500.0f;
-        v.y = __fdiv_rn(v.y, speed) * 500.0f;
+    if (MODE == 2) {
+        const float s2 = __builtin_fmaf(v.x, v.x, v.y * v.y);
+        if (s2 > 250000.0f) { const float k = 500.0f * __builtin_amdgcn_rsqf(s2); v.x *= k; v.y *= k; }
+    } else {
+        const float speed = sqrt_rn(v.x * v.x + v.y * v.y);
+        if (speed > 500.0f) {
+            v.x = __fdiv_rn(v.x, speed) * 500.0f;
+            v.y = __fdiv_rn(v.y, speed) * 500.0f;
+        }
     }
     p.x += v.x * P.dt;
     p.y += v.y * P.dt;
 
-    const float uvx = (__fdiv_rn(me.x, P.bounds_x) * 1.0f) + 0.5f;      // compute.wgsl:127
-    const float uvy = (__fdiv_rn(me.y, P.bounds_y) * 1.0f) + 0.5f;
-    const uint32_t px = f32_to_u32_sat(uvx * P.tex_w);
-    const uint32_t py = f32_to_u32_sat(uvy * P.tex_h);
-    const uint32_t tix = py * P.tex_w_u + px;
     float2 force = make_float2(0.0f, 0.0f);
-    if (tix < P.tex_len) force = tex[tix];
+    if (!P.tex_zero) {   // uniform; an all-zero field (the default, and the benchmark's) changes nothing below
+        const float uvx = (__fdiv_rn(me.x, P.bounds_x) * 1.0f) + 0.5f;      // compute.wgsl:127
+        const float uvy = (__fdiv_rn(me.y, P.bounds_y) * 1.0f) + 0.5f;
+        const uint32_t px = f32_to_u32_sat(uvx * P.tex_w);
+        const uint32_t py = f32_to_u32_sat(uvy * P.tex_h);
+        const uint32_t tix = py * P.tex_w_u + px;
+        if (tix < P.tex_len) force = tex[tix];
+    }
     if (force.x != 0.0f || force.y != 0.0f) {                           // compute.wgsl:131-140
         const float p2wx = __fdiv_rn(P.bounds_x * 2.0f, P.tex_w);
         const float p2wy = __fdiv_rn(P.bounds_y * 2.0f, P.tex_h);
@@ -647,7 +739,7 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
     if (aos_out) {   // uniform: a renderer hand-off is registered (fs_export_handle) — the 32-byte ParticleInstance the
                      // reference's fragment shader binds (src/simulation.rs:552-559) is written here, no export pass
         AosParticle a;
-        a.position = p; a.predicted = me; a.velocity = v; a.density = mrho;
+        a.position = p; a.predicted = me; a.velocity = v; a.density = MODE == 2 ? rho_arr[i] : mrho;
         a.grid = cy * P.grid_w + cx;      // == the sorted key: same expression as cell_of_point(pred) (single-domain handles only)
         aos_out[i] = a;
     }
@@ -807,19 +899,25 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
                     const uint32_t* start_ref, const u64* pairs, const unsigned char* safe, float* rho, float2* rho2) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
-    hipLaunchKernelGGL(k_density, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2);
+    if (P.fast_math == 2)
+        hipLaunchKernelGGL(k_density<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2);
+    else
+        hipLaunchKernelGGL(k_density<false>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2);
 }
 
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
-                  float2* pos_out, float2* vel_out, void* aos_out) {
+                  float2* pos_out, float2* vel_out, const float* rho_arr, void* aos_out) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
-    if (P.fast_math)
-        hipLaunchKernelGGL(k_force<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
-                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out);
+    if (P.fast_math == 2)
+        hipLaunchKernelGGL(k_force<2>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
+                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr);
+    else if (P.fast_math == 1)
+        hipLaunchKernelGGL(k_force<1>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
+                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr);
     else
-        hipLaunchKernelGGL(k_force<false>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
-                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out);
+        hipLaunchKernelGGL(k_force<0>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
+                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr);
 }
 
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,

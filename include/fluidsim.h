@@ -125,8 +125,12 @@ typedef enum fs_sort_mode {
 
 typedef enum fs_math_mode {
     FS_MATH_IEEE = 0,      /* correctly rounded / and sqrt, no contraction: bit-identical to the CPU oracle */
-    FS_MATH_WGSL_ULP = 1   /* native rcp / sqrt in the force pass (<= ~1.5 ulp): within WGSL's own accuracy
+    FS_MATH_WGSL_ULP = 1,  /* native rcp / sqrt in the force pass (<= ~1.5 ulp): within WGSL's own accuracy
                               contract for the reference shaders (division 2.5 ULP, sqrt 2 ULP), not bit-exact */
+    FS_MATH_TOLERANCE = 2  /* density and force terms re-associated for speed (FMA, one rsqrt per pair, pressure and
+                              1/density precomputed per particle): positions / velocities / densities within
+                              rtol 1e-5, atol 1e-4*h of the IEEE oracle per step (north_star's float contract);
+                              cell keys and start_indices remain bit-exact.  Never the default. */
 } fs_math_mode;
 
 typedef struct fs_options {

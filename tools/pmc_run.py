@@ -1,7 +1,7 @@
 """Workload for `rocprofv3 --pmc ... -- python3 tools/pmc_run.py <scene> [warm] [steps] [mode]`.
 scene: 2d (16M dam break) | 3d (8M dam break) | 2d1m.  The library must be built already: nothing is compiled
 here (the profiler's preload has initialised the GPU; exec'ing compilers from this process is not allowed).
-mode: strict (default) | counting | ulp | sym (tolerance-mode pair-symmetric force, when built)."""
+mode: strict (default) | counting | ulp | tol (FS_MATH_TOLERANCE)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import gpu_fluid_simulation_amd as g
@@ -18,7 +18,7 @@ else:
     kw = {}
     if mode == "counting": kw["sort_mode"] = g.FS_SORT_COUNTING
     if mode == "ulp": kw["math_mode"] = g.FS_MATH_WGSL_ULP
-    if mode == "sym": kw["math_mode"] = getattr(g, "FS_MATH_PAIR_SYMMETRIC")
+    if mode == "tol": kw["math_mode"] = g.FS_MATH_TOLERANCE
     sim = g.FluidSimulation(st, device=0, initial_offset=off, **kw)
 for _ in range(warm + steps):
     sim.tick(tick)
