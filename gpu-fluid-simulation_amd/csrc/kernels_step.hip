@@ -611,7 +611,7 @@ struct AosParticle { float2 position, predicted, velocity; float density; uint32
 #ifndef FS_FORCE_WAVES
 #define FS_FORCE_WAVES 8
 #endif
-template <int MODE>
+template <int MODE, bool AOS>
 __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FORCE_WAVES, FS_FORCE_WAVES))) void k_force(StepParams P, const float2* __restrict__ pos_s,
                                                     const float2* __restrict__ vel_s,
                                                     const float2* __restrict__ pred, const float2* __restrict__ rho2,
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
     if (fabsf(p.y) > P.bs_y) { p.y = P.bs_y * sign_f32(p.y); v.y *= -1.0f * P.damping; }
     pos_out[i] = p;
     vel_out[i] = v;
-    if (aos_out) {   // uniform: a renderer hand-off is registered (fs_export_handle) — the 32-byte ParticleInstance the
+    if (AOS) {       // compile-time (even unused, the store costs the plain kernel 5 %): a renderer hand-off is registered (fs_export_handle) — the 32-byte ParticleInstance the
                      // reference's fragment shader binds (src/simulation.rs:552-559) is written here, no export pass
         AosParticle a;
         a.position = p; a.predicted = me; a.velocity = v; a.density = MODE == 2 ? rho_arr[i] : mrho;
@@ -909,15 +909,13 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out, const float* rho_arr, void* aos_out) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
-    if (P.fast_math == 2)
-        hipLaunchKernelGGL(k_force<2>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
-                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr);
-    else if (P.fast_math == 1)
-        hipLaunchKernelGGL(k_force<1>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
-                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr);
-    else
-        hipLaunchKernelGGL(k_force<0>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,
-                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr);
+#define FS_LAUNCH_FORCE(M, A)                                                                                       \
+    hipLaunchKernelGGL((k_force<M, A>), dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs, start_ref,  \
+                       pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr)
+    if (P.fast_math == 2) { if (aos_out) FS_LAUNCH_FORCE(2, true); else FS_LAUNCH_FORCE(2, false); }
+    else if (P.fast_math == 1) { if (aos_out) FS_LAUNCH_FORCE(1, true); else FS_LAUNCH_FORCE(1, false); }
+    else { if (aos_out) FS_LAUNCH_FORCE(0, true); else FS_LAUNCH_FORCE(0, false); }
+#undef FS_LAUNCH_FORCE
 }
 
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
