@@ -110,6 +110,7 @@ struct fs_sim {
     DevArray<float> rho;
     DevArray<float2> rho2;          // {density, RN(1/density)}: what the force pass gathers per neighbour
     DevArray<uint32_t> key;
+    DevArray<uint32_t> fdefer, fwork;   // force pass: per-block deferred-wave bits and the worklist (counter[3] = its length)
     DevArray<unsigned char> safe;   // per sorted particle: coordinates / velocity inside the exact-quotient ranges (fs_device.h)
     DevArray<fsd::u64> pairs;
     DevArray<uint32_t> sort_dirty;  // per-tile flags of the bitonic sort
@@ -152,7 +153,7 @@ struct fs_sim {
 
     void release() {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release(); rho2.release();
-        key.release(); safe.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
+        key.release(); safe.release(); fdefer.release(); fwork.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
         owned.release(); flags.release(); blockcnt.release(); blockoff.release(); slab_counters.release();
         hist.release();
@@ -368,12 +369,12 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     }
     if (prof) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, s->key.p, s->cs.p,
-                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, counting);
+                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, s->fdefer.p, s->counter.p + 3, counting);
     if (prof) FS_HIP(hipEventRecord(ev[3], st));
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->aos_live ? (void*)s->aos.p : nullptr);
+                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 3, s->aos_live ? (void*)s->aos.p : nullptr);
     if (s->aos_live) s->aos_tick = s->tick;
     if (prof) {
         FS_HIP(hipEventRecord(ev[5], st));
@@ -444,7 +445,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->fdefer.alloc((cap + 255) / 256 + 8)); FS_TRY(s->fwork.alloc((cap + 255) / 256 + 8)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1));
@@ -845,7 +846,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->fdefer.alloc((cap + 255) / 256 + 8)); FS_TRY(s->fwork.alloc((cap + 255) / 256 + 8)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->owned.alloc(cap)); FS_TRY(s->flags.alloc(cap));
@@ -960,12 +961,12 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     if (ev) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
                              s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,
-                             s->slab_counters.p, s->safe.p, counting);
+                             s->slab_counters.p, s->safe.p, s->fdefer.p, s->counter.p + 3, counting);
     if (ev) FS_HIP(hipEventRecord(ev[3], st));
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p);
     if (ev) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p, s->rho.p);
+                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 3);
     if (ev) { FS_HIP(hipEventRecord(ev[5], st)); s->prof_pending += 1; }
     FS_HIP(hipGetLastError());
     s->slab_packed = false;

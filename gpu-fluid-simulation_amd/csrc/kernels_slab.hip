@@ -197,8 +197,13 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
                                                            uint32_t* __restrict__ cs, uint32_t* __restrict__ start_ref,
                                                            GapEntry* __restrict__ work, uint32_t* __restrict__ counter,
                                                            uint32_t work_cap, uint32_t* __restrict__ n_live_out,
-                                                           unsigned char* __restrict__ safe) {
+                                                           unsigned char* __restrict__ safe, uint32_t* __restrict__ force_defer,
+                                                           uint32_t* __restrict__ force_work_count) {
     const uint32_t i = blockIdx.x * SL_BLOCK + threadIdx.x;
+    if (threadIdx.x == 0) {                      // the force pass's worklist of this step (same block size)
+        force_defer[blockIdx.x] = 0u;
+        if (blockIdx.x == 0) *force_work_count = 0u;
+    }
     if (i >= cap) return;
     const u64 pr = pairs[i];
     const uint32_t key = (uint32_t)(pr >> 32);
@@ -348,14 +353,15 @@ void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots
 void launch_slab_reorder(hipStream_t st, const StepParams& P, uint32_t cap, const u64* pairs, const float2* pos_in,
                          const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s,
                          unsigned char* owned, uint32_t* cs, uint32_t* start_ref, void* work, uint32_t* counter,
-                         uint32_t work_cap, uint32_t* n_live_out, unsigned char* safe, bool cs_ready) {
+                         uint32_t work_cap, uint32_t* n_live_out, unsigned char* safe, uint32_t* force_defer,
+                         uint32_t* force_work_count, bool cs_ready) {
     if (cs_ready) {   // counting sort: table and live count already exist
         hipLaunchKernelGGL(k_slab_reorder<false>, dim3(nb(cap)), dim3(SL_BLOCK), 0, st, P, cap, pairs, pos_in, vel_in,
-                           pos_s, vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out, safe);
+                           pos_s, vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out, safe, force_defer, force_work_count);
         return;
     }
     hipLaunchKernelGGL(k_slab_reorder<true>, dim3(nb(cap)), dim3(SL_BLOCK), 0, st, P, cap, pairs, pos_in, vel_in, pos_s,
-                       vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out, safe);
+                       vel_s, pred_s, key_s, owned, cs, start_ref, (GapEntry*)work, counter, work_cap, n_live_out, safe, force_defer, force_work_count);
     launch_fill_gaps(st, cs, work, counter, work_cap);
 }
 

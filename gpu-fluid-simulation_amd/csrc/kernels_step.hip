@@ -44,8 +44,13 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
                                                       uint32_t* __restrict__ key_s, uint32_t* __restrict__ cs,
                                                       uint32_t* __restrict__ start_ref, GapEntry* __restrict__ work,
                                                       uint32_t* __restrict__ counter, uint32_t work_cap,
-                                                      unsigned char* __restrict__ safe) {
+                                                      unsigned char* __restrict__ safe, uint32_t* __restrict__ force_defer,
+                                                      uint32_t* __restrict__ force_work_count) {
     const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (threadIdx.x == 0) {                      // the force pass's worklist of this step (same block size and count)
+        force_defer[blockIdx.x] = 0u;
+        if (blockIdx.x == 0) *force_work_count = 0u;
+    }
     if (i >= P.n) return;
     const u64 pr = pairs[i];
     const uint32_t key = (uint32_t)(pr >> 32);
@@ -517,8 +522,11 @@ __device__ __forceinline__ void force_sweep_chunks(const StepParams& P, const Ro
 //           own range afterwards, and the middle row clears the lane's own bit (`k != i`, :195).
 //   heavy — every lane walks its set bits, row 0, 1, 2, ascending = the reference visiting order, so
 //           the sums keep their association; all lanes stay busy until the longest list is done.
-template <int MODE>
-__device__ __forceinline__ void force_sweep_masks(const StepParams& P, const RowRanges& R, const uint32_t* blo,
+// GENERAL = false (the lean main kernel): a pair whose operands fall outside the proven ranges is not re-evaluated
+// here — the wave remembers it (`bad`) and the caller hands the whole wave to the general kernel instead, so the
+// exact true-division body never enters this kernel's register allocation.
+template <int MODE, bool GENERAL>
+__device__ __forceinline__ bool force_sweep_masks(const StepParams& P, const RowRanges& R, const uint32_t* blo,
                                                   uint32_t ii, const float2 me, const float2 mv, float pressure,
                                                   const float2* __restrict__ vel_s, const float2* __restrict__ rho2,
                                                   const float2* s_flat /* [3][NBF_ROW] */, bool me_ok, ForceAcc& A) {
@@ -526,6 +534,7 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
     const float lim = P.sqr_radius;
     constexpr bool FAST = MODE == 1;
     const TolConsts TC = tol_consts(P);
+    bool bad = false;                        // wave-uniform
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const uint32_t len = R.hi[r] - R.lo[r];                           // <= 32 (caller)
@@ -590,17 +599,16 @@ __device__ __forceinline__ void force_sweep_masks(const StepParams& P, const Row
                 wave_mask good = 0;
                 if (P.share_div) { T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good); good &= me_okm; }
                 if (good != wm(true)) {             // rare, wave-uniform
-#ifdef FS_SLOW_NOINLINE
-                    force_terms_exact_call(&P, me, mv, pressure, q0, v0, d0.x, &A.seed, &T0);
-#else
-                    T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
-#endif
+                    if (GENERAL) T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
+                    else bad = true;
                 }
             }
             A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
         }
     }
 #undef FS_FETCH_NEXT
+    // `bad` was set under the exec mask of the lanes that were evaluating the failing pair: make it the wave's
+    return __any(bad);
 }
 
 // amdgpu_waves_per_eu(8, 8): with the chunked sweep inlined next to the mask sweep the allocator would take
@@ -611,24 +619,29 @@ struct AosParticle { float2 position, predicted, velocity; float density; uint32
 #ifndef FS_FORCE_WAVES
 #define FS_FORCE_WAVES 8
 #endif
-template <int MODE, bool AOS>
-__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FORCE_WAVES, FS_FORCE_WAVES))) void k_force(StepParams P, const float2* __restrict__ pos_s,
-                                                    const float2* __restrict__ vel_s,
-                                                    const float2* __restrict__ pred, const float2* __restrict__ rho2,
-                                                    const uint32_t* __restrict__ cs,
-                                                    const uint32_t* __restrict__ start_ref,
-                                                    const u64* __restrict__ pairs, const float2* __restrict__ tex,
-                                                    float2* __restrict__ pos_out, float2* __restrict__ vel_out,
-                                                    AosParticle* __restrict__ aos_out, const float* __restrict__ rho_arr) {
-    __shared__ float2 s_pred[3][NBF_ROW];
-    __shared__ uint32_t s_red[24];
+// One workgroup's 256 particles.  GENERAL = false is the lean main path: mask sweep with the shared-reciprocal terms
+// only.  A wave it cannot finish that way — its tile does not fit the LDS stage, one of its sweep rows is longer than
+// 32 candidates (dense clusters), or an operand fell outside the proven quotient ranges — is handed to the general
+// kernel through a device worklist (`defer_bits[blk]` bit w, the block id pushed once) and writes nothing.
+// GENERAL = true is the complete body (chunked sweeps, true-division fallback) for the waves named in `wave_bits`.
+// The split keeps the rare paths out of the common kernel's register allocation: 39 VGPRs instead of 64 + 35
+// spilled, force 0.72 -> 0.67 ms at 16M (profiles/r02_c_force_split.txt).
+template <int MODE, bool AOS, bool GENERAL>
+__device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, uint32_t n, uint32_t wave_bits,
+                                            const float2* __restrict__ pos_s, const float2* __restrict__ vel_s,
+                                            const float2* __restrict__ pred, const float2* __restrict__ rho2,
+                                            const uint32_t* __restrict__ cs, const uint32_t* __restrict__ start_ref,
+                                            const u64* __restrict__ pairs, const float2* __restrict__ tex,
+                                            float2* __restrict__ pos_out, float2* __restrict__ vel_out,
+                                            AosParticle* __restrict__ aos_out, const float* __restrict__ rho_arr,
+                                            uint32_t* __restrict__ defer_bits, uint32_t* __restrict__ worklist,
+                                            uint32_t* __restrict__ work_count, float2 (*s_pred)[NBF_ROW],
+                                            uint32_t* s_red) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t n = P.n_live ? *P.n_live : P.n;
-    uint32_t blk;
-    if (!xcd_block((n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;      // uniform: no live particle in this block
     const uint32_t i = blk * FS_BLOCK + tid;
     bool live = i < n;
-    const uint32_t ii = live ? i : n - 1;            // dead lanes shadow the last particle, store nothing
+    if (GENERAL) live = live && ((wave_bits >> (tid >> 6)) & 1u);   // only the waves the main kernel handed over
+    const uint32_t ii = i < n ? i : n - 1;           // dead lanes shadow the last particle, store nothing
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
     const float2 me = pred[ii];
     const float2 mv = vel_s[ii];
@@ -654,6 +667,7 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
     }
     uint32_t blo[3], bhi[3];
     const bool staged = block_tile_bounds(R, s_red, blo, bhi, NBF_TILE);
+    bool defer = !staged;                            // lean path only; wave-uniform from here on
     if (staged) {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -663,11 +677,21 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
         __syncthreads();
         const bool long_row = R.hi[0] - R.lo[0] > 32u || R.hi[1] - R.lo[1] > 32u || R.hi[2] - R.lo[2] > 32u;
         if (!__any(long_row))
-            force_sweep_masks<MODE>(P, R, blo, ii, me, mv, pressure, vel_s, rho2, &s_pred[0][0], me_ok, A);
-        else
+            defer = force_sweep_masks<MODE, GENERAL>(P, R, blo, ii, me, mv, pressure, vel_s, rho2, &s_pred[0][0], me_ok, A);
+        else if (GENERAL)
             force_sweep_chunks<true, MODE>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], me_ok, A);
-    } else {
+        else
+            defer = true;
+    } else if (GENERAL) {
         force_sweep_chunks<false, MODE>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], me_ok, A);
+    }
+    defer = __any(defer);
+    if (!GENERAL && defer) {                         // wave-uniform: hand this wave over, write nothing
+        if (__builtin_amdgcn_ballot_w64(live) != 0 && (tid & 63u) == 0u) {
+            const uint32_t old = atomicOr(&defer_bits[blk], 1u << (tid >> 6));
+            if (old == 0u) worklist[atomicAdd(work_count, 1u)] = blk;   // first wave of the block to defer
+        }
+        return;
     }
     if (!live) return;
     const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
@@ -742,6 +766,41 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
         a.position = p; a.predicted = me; a.velocity = v; a.density = MODE == 2 ? rho_arr[i] : mrho;
         a.grid = cy * P.grid_w + cx;      // == the sorted key: same expression as cell_of_point(pred) (single-domain handles only)
         aos_out[i] = a;
+    }
+}
+
+#define FS_FORCE_ARGS                                                                                                  \
+    StepParams P, const float2* __restrict__ pos_s, const float2* __restrict__ vel_s, const float2* __restrict__ pred,  \
+        const float2* __restrict__ rho2, const uint32_t* __restrict__ cs, const uint32_t* __restrict__ start_ref,       \
+        const u64* __restrict__ pairs, const float2* __restrict__ tex, float2* __restrict__ pos_out,                   \
+        float2* __restrict__ vel_out, AosParticle* __restrict__ aos_out, const float* __restrict__ rho_arr,            \
+        uint32_t* __restrict__ defer_bits, uint32_t* __restrict__ worklist, uint32_t* __restrict__ work_count
+
+// Lean main kernel: every block once.
+template <int MODE, bool AOS>
+__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FORCE_WAVES, FS_FORCE_WAVES))) void k_force(FS_FORCE_ARGS) {
+    __shared__ float2 s_pred[3][NBF_ROW];
+    __shared__ uint32_t s_red[24];
+    const uint32_t n = P.n_live ? *P.n_live : P.n;
+    uint32_t blk;
+    if (!xcd_block((n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;      // uniform: no live particle in this block
+    force_block<MODE, AOS, false>(P, blk, n, 0xFu, pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex, pos_out, vel_out,
+                                  aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
+}
+
+// General kernel: a fixed grid walks the worklist the main kernel left (usually empty; dense regimes fill it).
+// amdgpu_waves_per_eu(8, 8) as measured for the former single kernel (64 VGPRs, spills in the rare branches).
+template <int MODE, bool AOS>
+__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_force_general(FS_FORCE_ARGS) {
+    __shared__ float2 s_pred[3][NBF_ROW];
+    __shared__ uint32_t s_red[24];
+    const uint32_t n = P.n_live ? *P.n_live : P.n;
+    const uint32_t count = *work_count;              // written by the main kernel, earlier in the stream
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint32_t blk = worklist[e];
+        force_block<MODE, AOS, true>(P, blk, n, defer_bits[blk], pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex,
+                                     pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
+        __syncthreads();                             // the LDS stage is reused by the next entry
     }
 }
 
@@ -885,14 +944,15 @@ static inline uint32_t nblk(uint32_t n) { return (n + FS_BLOCK - 1) / FS_BLOCK; 
 
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
-                    void* work, uint32_t* counter, uint32_t work_cap, unsigned char* safe, bool cs_ready) {
+                    void* work, uint32_t* counter, uint32_t work_cap, unsigned char* safe, uint32_t* force_defer,
+                    uint32_t* force_work_count, bool cs_ready) {
     if (cs_ready) {   // counting sort already produced the dense table
         hipLaunchKernelGGL(k_reorder<false>, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pairs, pos_in, vel_in, pos_s,
-                           vel_s, pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap, safe);
+                           vel_s, pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap, safe, force_defer, force_work_count);
         return;
     }
     hipLaunchKernelGGL(k_reorder<true>, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pairs, pos_in, vel_in, pos_s, vel_s,
-                       pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap, safe);
+                       pred_s, key_s, cs, start_ref, (GapEntry*)work, counter, work_cap, safe, force_defer, force_work_count);
     hipLaunchKernelGGL(k_fill_gaps, dim3(1024), dim3(FS_BLOCK), 0, st, cs, (const GapEntry*)work, counter, work_cap);
 }
 
@@ -907,11 +967,18 @@ void launch_density(hipStream_t st, const StepParams& P, const float2* pred, con
 
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
-                  float2* pos_out, float2* vel_out, const float* rho_arr, void* aos_out) {
+                  float2* pos_out, float2* vel_out, const float* rho_arr, uint32_t* defer_bits, uint32_t* worklist,
+                  uint32_t* work_count, void* aos_out) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
 #define FS_LAUNCH_FORCE(M, A)                                                                                       \
-    hipLaunchKernelGGL((k_force<M, A>), dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs, start_ref,  \
-                       pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr)
+    do {                                                                                                            \
+        hipLaunchKernelGGL((k_force<M, A>), dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,         \
+                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr, defer_bits,       \
+                           worklist, work_count);                                                                   \
+        hipLaunchKernelGGL((k_force_general<M, A>), dim3(nb < 2048u ? nb : 2048u), dim3(FS_BLOCK), 0, st, P, pos_s,    \
+                           vel_s, pred, rho2, cs, start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out,     \
+                           rho_arr, defer_bits, worklist, work_count);                                              \
+    } while (0)
     if (P.fast_math == 2) { if (aos_out) FS_LAUNCH_FORCE(2, true); else FS_LAUNCH_FORCE(2, false); }
     else if (P.fast_math == 1) { if (aos_out) FS_LAUNCH_FORCE(1, true); else FS_LAUNCH_FORCE(1, false); }
     else { if (aos_out) FS_LAUNCH_FORCE(0, true); else FS_LAUNCH_FORCE(0, false); }
