@@ -102,6 +102,8 @@ struct fs_sim {
     uint32_t tick = 0;
     fs_uniform uniform{};
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;     // second stream of the force pass (general workgroups beside the lean kernel)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int device = 0;
 
     // SoA state.  pos/vel: current state (cell order of the last step).  *_s: the
@@ -161,8 +163,11 @@ struct fs_sim {
         ev.clear();
         if (t0) (void)hipEventDestroy(t0);
         if (t1) (void)hipEventDestroy(t1);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
         if (stream) (void)hipStreamDestroy(stream);
-        stream = nullptr;
+        stream = nullptr; side = nullptr; ev_fork = ev_join = nullptr;
     }
 };
 
@@ -369,12 +374,12 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     }
     if (prof) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, s->key.p, s->cs.p,
-                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, s->fdefer.p, s->counter.p + 3, counting);
+                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, s->fdefer.p, s->counter.p + 4, counting);
     if (prof) FS_HIP(hipEventRecord(ev[3], st));
-    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p);
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 3, s->aos_live ? (void*)s->aos.p : nullptr);
+                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, s->aos_live ? (void*)s->aos.p : nullptr, s->side, s->ev_fork, s->ev_join);
     if (s->aos_live) s->aos_tick = s->tick;
     if (prof) {
         FS_HIP(hipEventRecord(ev[5], st));
@@ -443,16 +448,25 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     } while (0)
 
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    // The pre-registered general work can run beside the lean force kernel on a second stream (FS_SIDE_STREAM=1).
+    // Measured at 16M: force 0.725 -> 0.711 ms in the bench window and 1.10 -> 0.99 ms in the dense regime, but every
+    // launch of the following sort then pays ~1 us more behind the cross-stream join (sort 0.70 -> 0.73 ms): a net
+    // loss in the bench window, so it is off by default.
+    if (getenv("FS_SIDE_STREAM")) {
+        FS_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        FS_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        FS_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->fdefer.alloc((cap + 255) / 256 + 8)); FS_TRY(s->fwork.alloc((cap + 255) / 256 + 8)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1));
     FS_TRY(s->start_ref.alloc(s->ncell));
     FS_TRY(s->tex.alloc((size_t)settings->texture_size.x * settings->texture_size.y));
     FS_TRY(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
-    FS_TRY(s->counter.alloc(4));
+    FS_TRY(s->counter.alloc(8));
     if (opts->sort_mode == FS_SORT_COUNTING) FS_TRY(s->csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
     FS_TRY(hipEventCreate(&s->t0));
     FS_TRY(hipEventCreate(&s->t1));
@@ -460,7 +474,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     FS_TRY(hipMemsetAsync(s->start_ref.p, 0, s->start_ref.n * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->cs.p, 0, s->cs.n * sizeof(uint32_t), s->stream));
     if (s->tex.n) FS_TRY(hipMemsetAsync(s->tex.p, 0, s->tex.n * sizeof(float2), s->stream));
-    FS_TRY(hipMemsetAsync(s->counter.p, 0, 4 * sizeof(uint32_t), s->stream));
+    FS_TRY(hipMemsetAsync(s->counter.p, 0, 8 * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->rho.p, 0, cap * sizeof(float), s->stream));
     FS_TRY(hipMemsetAsync(s->key.p, 0, cap * sizeof(uint32_t), s->stream));
 
@@ -844,9 +858,18 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
                              std::string(#expr) + ": " + hipGetErrorString(e__)));                            \
     } while (0)
     FS_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    // The pre-registered general work can run beside the lean force kernel on a second stream (FS_SIDE_STREAM=1).
+    // Measured at 16M: force 0.725 -> 0.711 ms in the bench window and 1.10 -> 0.99 ms in the dense regime, but every
+    // launch of the following sort then pays ~1 us more behind the cross-stream join (sort 0.70 -> 0.73 ms): a net
+    // loss in the bench window, so it is off by default.
+    if (getenv("FS_SIDE_STREAM")) {
+        FS_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        FS_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        FS_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->fdefer.alloc((cap + 255) / 256 + 8)); FS_TRY(s->fwork.alloc((cap + 255) / 256 + 8)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->owned.alloc(cap)); FS_TRY(s->flags.alloc(cap));
@@ -858,13 +881,13 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1)); FS_TRY(s->start_ref.alloc(s->ncell));
     FS_TRY(s->tex.alloc((size_t)settings->texture_size.x * settings->texture_size.y));
     FS_TRY(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
-    FS_TRY(s->counter.alloc(4));
+    FS_TRY(s->counter.alloc(8));
     FS_TRY(s->aos.alloc(cap));
     FS_TRY(hipEventCreate(&s->t0)); FS_TRY(hipEventCreate(&s->t1));
     FS_TRY(hipMemsetAsync(s->start_ref.p, 0, s->start_ref.n * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->cs.p, 0, s->cs.n * sizeof(uint32_t), s->stream));
     if (s->tex.n) FS_TRY(hipMemsetAsync(s->tex.p, 0, s->tex.n * sizeof(float2), s->stream));
-    FS_TRY(hipMemsetAsync(s->counter.p, 0, 4 * sizeof(uint32_t), s->stream));
+    FS_TRY(hipMemsetAsync(s->counter.p, 0, 8 * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->slab_counters.p, 0, 8 * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->owned.p, 0, cap, s->stream));
     FS_TRY(hipMemsetAsync(s->flags.p, 0, cap, s->stream));
@@ -961,12 +984,13 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     if (ev) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
                              s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,
-                             s->slab_counters.p, s->safe.p, s->fdefer.p, s->counter.p + 3, counting);
+                             s->slab_counters.p, s->safe.p, s->fdefer.p, s->counter.p + 4, counting);
     if (ev) FS_HIP(hipEventRecord(ev[3], st));
-    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p);
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
     if (ev) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 3);
+                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
+                      s->ev_fork, s->ev_join);
     if (ev) { FS_HIP(hipEventRecord(ev[5], st)); s->prof_pending += 1; }
     FS_HIP(hipGetLastError());
     s->slab_packed = false;

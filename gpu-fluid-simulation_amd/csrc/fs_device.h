@@ -189,13 +189,14 @@ __device__ __forceinline__ bool kin_safe(float2 pred, float2 vel) {
 // them.  `nblocks` = blocks that hold live particles (in slab mode the grid covers the whole
 // capacity; mapping over that would park the dead tail on the last XCDs and idle them).  The
 // grid must have at least ceil(nblocks/8)*8 blocks; returns false for blocks with no work.
-__device__ __forceinline__ bool xcd_block(uint32_t nblocks, uint32_t* logical) {
+__device__ __forceinline__ bool xcd_block_at(uint32_t bid, uint32_t nblocks, uint32_t* logical) {
     const uint32_t per = (nblocks + 7u) >> 3;
-    const uint32_t slot = blockIdx.x >> 3;
-    const uint32_t lb = (blockIdx.x & 7u) * per + slot;
+    const uint32_t slot = bid >> 3;
+    const uint32_t lb = (bid & 7u) * per + slot;        // bid & 7 == blockIdx.x & 7 as long as the offset is a multiple of 8
     *logical = lb;
     return slot < per && lb < nblocks;
 }
+__device__ __forceinline__ bool xcd_block(uint32_t nblocks, uint32_t* logical) { return xcd_block_at(blockIdx.x, nblocks, logical); }
 
 // ---- block neighbour tiles (shared by the 2D and 3D density / force kernels) ------------------
 // A 256-thread workgroup owns 256 consecutive sorted particles (a strip of cells in one grid

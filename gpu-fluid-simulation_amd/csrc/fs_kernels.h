@@ -11,18 +11,21 @@ namespace fsd {
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
                     void* work, uint32_t* counter, uint32_t work_cap, unsigned char* safe /* kin_safe per sorted particle */,
-                    uint32_t* force_defer /* one word per 256-particle block */, uint32_t* force_work_count,
+                    uint32_t* force_defer /* two words per 256-particle block */, uint32_t* force_work_count /* [2] */,
                     bool cs_ready = false);
 // the chunked sweep of k_force reads up to 35 candidates past a row range when it scans global memory
 #define FS_PRED_SLACK 64
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
                     const uint32_t* start_ref, const u64* pairs, const unsigned char* safe, float* rho,
-                    float2* rho2 /* {rho, +-RN(1/rho)}: the sign is the particle's safe-operand classification */);
+                    float2* rho2 /* {rho, +-RN(1/rho)}: the sign is the particle's safe-operand classification */,
+                    uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count /* force pass: pre-registered waves */);
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out, const float* rho_arr, uint32_t* defer_bits /* per block */,
                   uint32_t* worklist /* per block */, uint32_t* work_count,
-                  void* aos_out = nullptr /* 32-B ParticleInstance records, or none */);
+                  void* aos_out = nullptr /* 32-B ParticleInstance records, or none */,
+                  hipStream_t side = nullptr /* second stream: the pre-registered general work runs beside the lean kernel */,
+                  hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
                        const float* rho, const uint32_t* key, void* out);
 void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, float2* pred, float2* vel, float* rho,

@@ -47,9 +47,10 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
                                                       unsigned char* __restrict__ safe, uint32_t* __restrict__ force_defer,
                                                       uint32_t* __restrict__ force_work_count) {
     const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
-    if (threadIdx.x == 0) {                      // the force pass's worklist of this step (same block size and count)
-        force_defer[blockIdx.x] = 0u;
-        if (blockIdx.x == 0) *force_work_count = 0u;
+    if (threadIdx.x == 0) {                      // the force pass's worklists of this step (same block size and count)
+        force_defer[2u * blockIdx.x] = 0u;       // [2 blk] pre-registered by k_density, [2 blk + 1] found late by k_force
+        force_defer[2u * blockIdx.x + 1u] = 0u;
+        if (blockIdx.x == 0) { force_work_count[0] = 0u; force_work_count[1] = 0u; }
     }
     if (i >= P.n) return;
     const u64 pr = pairs[i];
@@ -122,6 +123,9 @@ __device__ __forceinline__ bool row_range(const StepParams& P, const uint32_t* _
 // per-lane loops then read LDS instead of issuing one gather per candidate.  Strips that
 // straddle a grid-row end (or very sparse ones) exceed the tile and take the global path.
 #define NB_TILE 640          // staged candidates per sweep row
+#ifndef NBF_TILE
+#define NBF_TILE 384         // ... of the force pass (k_force)
+#endif
 
 // -------------------------------------------------------------------- density
 __device__ __forceinline__ float density_cube_tol(float h2, float2 me, float2 q, float acc) {
@@ -149,7 +153,8 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
                                                       const uint32_t* __restrict__ start_ref,
                                                       const u64* __restrict__ pairs, const unsigned char* __restrict__ safe,
                                                       float* __restrict__ rho_out,
-                                                      float2* __restrict__ rho2_out) {
+                                                      float2* __restrict__ rho2_out, uint32_t* __restrict__ force_defer,
+                                                      uint32_t* __restrict__ force_work, uint32_t* __restrict__ force_count) {
     __shared__ float2 s_pred[3][NB_TILE];
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
@@ -171,6 +176,16 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
     }
     uint32_t blo[3], bhi[3];
     const bool fit = block_tile_bounds(R, s_red, blo, bhi, NB_TILE);
+    {   // The force pass sweeps the same row ranges: a wave it could not finish on its lean path — a row longer than
+        // 32 candidates, or a block whose rows do not fit ITS LDS stage — is named here already, so that the general
+        // workgroups of the force launch can start on it at once, beside the lean ones (k_force).
+        const bool unfit = bhi[0] - blo[0] > NBF_TILE || bhi[1] - blo[1] > NBF_TILE || bhi[2] - blo[2] > NBF_TILE;
+        const bool long_row = R.hi[0] - R.lo[0] > 32u || R.hi[1] - R.lo[1] > 32u || R.hi[2] - R.lo[2] > 32u;
+        if ((unfit || __any(long_row)) && __builtin_amdgcn_ballot_w64(live) != 0 && (threadIdx.x & 63u) == 0u) {
+            const uint32_t old = atomicOr(&force_defer[2u * blk], 1u << (threadIdx.x >> 6));
+            if (old == 0u) force_work[atomicAdd(&force_count[0], 1u)] = blk;
+        }
+    }
     float rho = 0.0f;
     if (fit) {
 #pragma unroll
@@ -408,9 +423,6 @@ __device__ __forceinline__ ForceTerms force_terms_shared(const StepParams& P, co
 // NBF_PAD of slack (the mask scans read up to 32 entries from a range start, whatever the range's length).
 // Velocity and {density, 1/density} of the few in-radius neighbours are gathered in the heavy phase instead
 // (staging them too cost occupancy and measured slower).
-#ifndef NBF_TILE
-#define NBF_TILE 384
-#endif
 #define NBF_PAD 32u
 #define NBF_ROW (NBF_TILE + NBF_PAD)     // LDS row pitch
 
@@ -626,6 +638,8 @@ struct AosParticle { float2 position, predicted, velocity; float density; uint32
 // GENERAL = true is the complete body (chunked sweeps, true-division fallback) for the waves named in `wave_bits`.
 // The split keeps the rare paths out of the common kernel's register allocation: 39 VGPRs instead of 64 + 35
 // spilled, force 0.72 -> 0.67 ms at 16M (profiles/r02_c_force_split.txt).
+// defer_bits[2 blk] / worklist[0 .. nblk) / work_count[0]: waves named by k_density before the launch ("pre");
+// defer_bits[2 blk + 1] / worklist[nblk ..) / work_count[1]: waves the lean path gives up on itself ("late").
 template <int MODE, bool AOS, bool GENERAL>
 __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, uint32_t n, uint32_t wave_bits,
                                             const float2* __restrict__ pos_s, const float2* __restrict__ vel_s,
@@ -640,7 +654,10 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blk * FS_BLOCK + tid;
     bool live = i < n;
-    if (GENERAL) live = live && ((wave_bits >> (tid >> 6)) & 1u);   // only the waves the main kernel handed over
+    if (GENERAL) live = live && ((wave_bits >> (tid >> 6)) & 1u);   // only the waves handed over to the general path
+    // lean path: a wave k_density pre-registered is being finished by a general workgroup of this same launch
+    const bool pre = !GENERAL && ((wave_bits >> (tid >> 6)) & 1u);
+    if (pre) live = false;
     const uint32_t ii = i < n ? i : n - 1;           // dead lanes shadow the last particle, store nothing
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
     const float2 me = pred[ii];
@@ -686,10 +703,10 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
         force_sweep_chunks<false, MODE>(P, R, blo, ii, me, mv, pressure, pred, vel_s, rho2, &s_pred[0][0], me_ok, A);
     }
     defer = __any(defer);
-    if (!GENERAL && defer) {                         // wave-uniform: hand this wave over, write nothing
+    if (!GENERAL && defer) {                         // wave-uniform: hand this wave over (late list), write nothing
         if (__builtin_amdgcn_ballot_w64(live) != 0 && (tid & 63u) == 0u) {
-            const uint32_t old = atomicOr(&defer_bits[blk], 1u << (tid >> 6));
-            if (old == 0u) worklist[atomicAdd(work_count, 1u)] = blk;   // first wave of the block to defer
+            const uint32_t old = atomicOr(&defer_bits[2u * blk + 1u], 1u << (tid >> 6));
+            if (old == 0u) worklist[P.n / FS_BLOCK + 8u + atomicAdd(&work_count[1], 1u)] = blk;   // first wave of the block
         }
         return;
     }
@@ -776,30 +793,38 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
         float2* __restrict__ vel_out, AosParticle* __restrict__ aos_out, const float* __restrict__ rho_arr,            \
         uint32_t* __restrict__ defer_bits, uint32_t* __restrict__ worklist, uint32_t* __restrict__ work_count
 
-// Lean main kernel: every block once.
+// Lean main kernel: every block once — mask sweep + shared reciprocals only, skipping the waves k_density
+// pre-registered.  (Folding the general workgroups into this launch was tried: the kernel then carries the general
+// body's spills and scratch set-up and the strict lean path ran 1.7x slower; two kernels on two streams instead.)
 template <int MODE, bool AOS>
-__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FORCE_WAVES, FS_FORCE_WAVES))) void k_force(FS_FORCE_ARGS) {
+__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FORCE_WAVES, FS_FORCE_WAVES))) void k_force(FS_FORCE_ARGS, uint32_t which) {
     __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
     uint32_t blk;
     if (!xcd_block((n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;      // uniform: no live particle in this block
-    force_block<MODE, AOS, false>(P, blk, n, 0xFu, pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex, pos_out, vel_out,
-                                  aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
+    force_block<MODE, AOS, false>(P, blk, n, defer_bits[2u * blk], pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex,
+                                  pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
 }
 
-// General kernel: a fixed grid walks the worklist the main kernel left (usually empty; dense regimes fill it).
+// General kernel: a fixed grid walks one of the two worklists with the complete body.
+//   which = 0: the waves k_density pre-registered (long rows / unstaged tiles: dense clusters) — launched on the
+//              simulation's second stream so that it runs BESIDE the lean kernel: a general workgroup's latency (a wave
+//              alone with 100+ neighbours per particle) hides under the lean work;
+//   which = 1: the waves the lean kernel gave up on itself (an operand outside the proven quotient ranges) — after
+//              both, on the main stream; usually empty.
 // amdgpu_waves_per_eu(8, 8) as measured for the former single kernel (64 VGPRs, spills in the rare branches).
 template <int MODE, bool AOS>
-__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_force_general(FS_FORCE_ARGS) {
+__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_force_general(FS_FORCE_ARGS, uint32_t which) {
     __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
-    const uint32_t count = *work_count;              // written by the main kernel, earlier in the stream
+    const uint32_t count = work_count[which];        // written earlier in the stream (k_density / the lean kernel)
+    const uint32_t* list = worklist + (which ? P.n / FS_BLOCK + 8u : 0u);
     for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-        const uint32_t blk = worklist[e];
-        force_block<MODE, AOS, true>(P, blk, n, defer_bits[blk], pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex,
-                                     pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
+        const uint32_t blk = list[e];
+        force_block<MODE, AOS, true>(P, blk, n, defer_bits[2u * blk + which], pos_s, vel_s, pred, rho2, cs, start_ref, pairs,
+                                     tex, pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
         __syncthreads();                             // the LDS stage is reused by the next entry
     }
 }
@@ -957,31 +982,41 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
 }
 
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
-                    const uint32_t* start_ref, const u64* pairs, const unsigned char* safe, float* rho, float2* rho2) {
+                    const uint32_t* start_ref, const u64* pairs, const unsigned char* safe, float* rho, float2* rho2,
+                    uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
     if (P.fast_math == 2)
-        hipLaunchKernelGGL(k_density<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2);
+        hipLaunchKernelGGL(k_density<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
     else
-        hipLaunchKernelGGL(k_density<false>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2);
+        hipLaunchKernelGGL(k_density<false>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
 }
 
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out, const float* rho_arr, uint32_t* defer_bits, uint32_t* worklist,
-                  uint32_t* work_count, void* aos_out) {
+                  uint32_t* work_count, void* aos_out, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
-#define FS_LAUNCH_FORCE(M, A)                                                                                       \
+#define FS_LAUNCH_FORCE(K, M, A, G, S, W)                                                                           \
+    hipLaunchKernelGGL((K<M, A>), dim3(G), dim3(FS_BLOCK), 0, S, P, pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex, \
+                       pos_out, vel_out, (AosParticle*)aos_out, rho_arr, defer_bits, worklist, work_count, W)
+#define FS_LAUNCH_FORCE_MODE(K, G, S, W)                                                                            \
     do {                                                                                                            \
-        hipLaunchKernelGGL((k_force<M, A>), dim3(grid), dim3(FS_BLOCK), 0, st, P, pos_s, vel_s, pred, rho2, cs,         \
-                           start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out, rho_arr, defer_bits,       \
-                           worklist, work_count);                                                                   \
-        hipLaunchKernelGGL((k_force_general<M, A>), dim3(nb < 2048u ? nb : 2048u), dim3(FS_BLOCK), 0, st, P, pos_s,    \
-                           vel_s, pred, rho2, cs, start_ref, pairs, tex, pos_out, vel_out, (AosParticle*)aos_out,     \
-                           rho_arr, defer_bits, worklist, work_count);                                              \
+        if (P.fast_math == 2) { if (aos_out) FS_LAUNCH_FORCE(K, 2, true, G, S, W); else FS_LAUNCH_FORCE(K, 2, false, G, S, W); } \
+        else if (P.fast_math == 1) { if (aos_out) FS_LAUNCH_FORCE(K, 1, true, G, S, W); else FS_LAUNCH_FORCE(K, 1, false, G, S, W); } \
+        else { if (aos_out) FS_LAUNCH_FORCE(K, 0, true, G, S, W); else FS_LAUNCH_FORCE(K, 0, false, G, S, W); }      \
     } while (0)
-    if (P.fast_math == 2) { if (aos_out) FS_LAUNCH_FORCE(2, true); else FS_LAUNCH_FORCE(2, false); }
-    else if (P.fast_math == 1) { if (aos_out) FS_LAUNCH_FORCE(1, true); else FS_LAUNCH_FORCE(1, false); }
-    else { if (aos_out) FS_LAUNCH_FORCE(0, true); else FS_LAUNCH_FORCE(0, false); }
+    const uint32_t gg = nb < 1024u ? nb : 1024u;
+    if (side) {   // fork: the pre-registered waves on the second stream, beside the lean kernel
+        (void)hipEventRecord(ev_fork, st);
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        FS_LAUNCH_FORCE_MODE(k_force_general, gg, side, 0u);
+        (void)hipEventRecord(ev_join, side);
+    }
+    FS_LAUNCH_FORCE_MODE(k_force, grid, st, 0u);
+    if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
+    else FS_LAUNCH_FORCE_MODE(k_force_general, gg, st, 0u);
+    FS_LAUNCH_FORCE_MODE(k_force_general, (nb < 256u ? nb : 256u), st, 1u);
+#undef FS_LAUNCH_FORCE_MODE
 #undef FS_LAUNCH_FORCE
 }
 
