@@ -250,6 +250,13 @@ fsd::StepParams make_params(const fs_sim& s) {
     P.tex_w_u = s.settings.texture_size.x;   // u32(u.texture_size.x), compute.wgsl:129
     P.tex_len = (uint32_t)s.tex.n;
     P.tex_zero = s.tex_zero ? 1 : 0;
+    {   // xcd_block(): chunks of ~1/64 of the strips, at most 256 blocks (8 grid rows of the 16M scene), at least 1
+        static const int forced = getenv("FS_XCD_CHUNK_LOG2") ? atoi(getenv("FS_XCD_CHUNK_LOG2")) : -1;
+        const uint32_t nb = (s.capacity + 255u) / 256u;
+        uint32_t c = 0;
+        while (c < 8u && (64u << (c + 1u)) <= nb) ++c;
+        P.xcd_chunk_log2 = forced >= 0 ? (uint32_t)forced : c;
+    }
     P.ref_quirks = s.opts.ref_quirks;
     P.fast_math = s.opts.math_mode == FS_MATH_WGSL_ULP ? 1 : s.opts.math_mode == FS_MATH_TOLERANCE ? 2 : 0;
     P.div_2h3 = s.div_2h3;

@@ -35,6 +35,7 @@ struct StepParams {
     uint32_t frame_time;
     float tex_w, tex_h;
     uint32_t tex_w_u, tex_len;
+    uint32_t xcd_chunk_log2;   // xcd_block(): blocks per chunk dealt to one XCD
     int32_t tex_zero;          // host knows the force field is all zeros: the lookup of compute.wgsl:127-140 is skipped
     int32_t ref_quirks;
     int32_t fast_math;         // FS_MATH_WGSL_ULP: native rcp/sqrt in the force pass (not bit-exact)
@@ -189,14 +190,20 @@ __device__ __forceinline__ bool kin_safe(float2 pred, float2 vel) {
 // them.  `nblocks` = blocks that hold live particles (in slab mode the grid covers the whole
 // capacity; mapping over that would park the dead tail on the last XCDs and idle them).  The
 // grid must have at least ceil(nblocks/8)*8 blocks; returns false for blocks with no work.
-__device__ __forceinline__ bool xcd_block_at(uint32_t bid, uint32_t nblocks, uint32_t* logical) {
-    const uint32_t per = (nblocks + 7u) >> 3;
-    const uint32_t slot = bid >> 3;
-    const uint32_t lb = (bid & 7u) * per + slot;        // bid & 7 == blockIdx.x & 7 as long as the offset is a multiple of 8
+// Chunked form (P.xcd_chunk_log2 = c): the strips are cut into chunks of 2^c blocks dealt round-robin to the XCDs, and an
+// XCD walks its chunks in order.  One contiguous eighth per XCD (c = large) minimises shared-row traffic but binds an
+// XCD to one region of the fluid: as the column compresses, the XCD that owns the bottom rows has several times the
+// neighbour pairs of the one that owns the surface and the launch waits for it.  Chunks of a few grid rows keep the
+// row sharing (a chunk re-reads one row above and one below) and spread every depth over all eight XCDs.
+// Grid: 8 * ceil(ceil(nblocks / 2^c) / 8) * 2^c blocks (xcd_grid()).
+__device__ __forceinline__ bool xcd_block(const StepParams& P, uint32_t nblocks, uint32_t* logical) {
+    const uint32_t c = P.xcd_chunk_log2;
+    const uint32_t slot = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const uint32_t chunk = ((slot >> c) << 3) | xcd;          // the XCD's (slot >> c)-th chunk
+    const uint32_t lb = (chunk << c) | (slot & ((1u << c) - 1u));
     *logical = lb;
-    return slot < per && lb < nblocks;
+    return lb < nblocks;
 }
-__device__ __forceinline__ bool xcd_block(uint32_t nblocks, uint32_t* logical) { return xcd_block_at(blockIdx.x, nblocks, logical); }
 
 // ---- block neighbour tiles (shared by the 2D and 3D density / force kernels) ------------------
 // A 256-thread workgroup owns 256 consecutive sorted particles (a strip of cells in one grid

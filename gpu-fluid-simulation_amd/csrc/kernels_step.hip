@@ -159,7 +159,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
     uint32_t blk;
-    if (!xcd_block((n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;      // uniform: no live particle in this block
+    if (!xcd_block(P, (n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;   // uniform: no live particle in this block
     const uint32_t i = blk * FS_BLOCK + threadIdx.x;
     const bool live = i < n;
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
     uint32_t blk;
-    if (!xcd_block((n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;      // uniform: no live particle in this block
+    if (!xcd_block(P, (n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;   // uniform: no live particle in this block
     force_block<MODE, AOS, false>(P, blk, n, defer_bits[2u * blk], pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex,
                                   pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
 }
@@ -966,6 +966,10 @@ void launch_render_density(hipStream_t st, const StepParams& P, float2 wmin, flo
 
 // ------------------------------------------------------------------ launchers
 static inline uint32_t nblk(uint32_t n) { return (n + FS_BLOCK - 1) / FS_BLOCK; }
+static inline uint32_t xcd_grid(uint32_t nb, uint32_t c) {      // blocks to launch for xcd_block() (fs_device.h)
+    const uint32_t chunks = (nb + (1u << c) - 1u) >> c;
+    return (((chunks + 7u) >> 3) << 3) << c;
+}
 
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
@@ -984,7 +988,7 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
                     const uint32_t* start_ref, const u64* pairs, const unsigned char* safe, float* rho, float2* rho2,
                     uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count) {
-    const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
+    const uint32_t nb = nblk(P.n), grid = xcd_grid(nb, P.xcd_chunk_log2);
     if (P.fast_math == 2)
         hipLaunchKernelGGL(k_density<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
     else
@@ -995,7 +999,7 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out, const float* rho_arr, uint32_t* defer_bits, uint32_t* worklist,
                   uint32_t* work_count, void* aos_out, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
-    const uint32_t nb = nblk(P.n), grid = ((nb + 7u) >> 3) << 3;      // padded to a multiple of 8 for xcd_block()
+    const uint32_t nb = nblk(P.n), grid = xcd_grid(nb, P.xcd_chunk_log2);
 #define FS_LAUNCH_FORCE(K, M, A, G, S, W)                                                                           \
     hipLaunchKernelGGL((K<M, A>), dim3(G), dim3(FS_BLOCK), 0, S, P, pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex, \
                        pos_out, vel_out, (AosParticle*)aos_out, rho_arr, defer_bits, worklist, work_count, W)
