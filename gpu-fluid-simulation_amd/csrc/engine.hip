@@ -113,7 +113,7 @@ struct fs_sim {
     DevArray<float2> rho2;          // {density, RN(1/density)}: what the force pass gathers per neighbour
     DevArray<uint32_t> key;
     DevArray<uint32_t> fdefer, fwork;   // force pass: per-block deferred-wave bits and the worklist (counter[3] = its length)
-    DevArray<unsigned char> safe;   // per sorted particle: coordinates / velocity inside the exact-quotient ranges (fs_device.h)
+    DevArray<unsigned long long> safe;   // one bit per sorted particle: coordinates / velocity inside the exact-quotient ranges (fs_device.h)
     DevArray<fsd::u64> pairs;
     DevArray<uint32_t> sort_dirty;  // per-tile flags of the bitonic sort
     DevArray<uint32_t> csort;       // scratch of the counting sort (FS_SORT_COUNTING)
@@ -466,7 +466,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     }
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc((cap + 63) / 64 + 1)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1));
@@ -876,7 +876,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     }
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc(cap)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc((cap + 63) / 64 + 1)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->owned.alloc(cap)); FS_TRY(s->flags.alloc(cap));

@@ -10,13 +10,13 @@ namespace fsd {
 
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
-                    void* work, uint32_t* counter, uint32_t work_cap, unsigned char* safe /* kin_safe per sorted particle */,
+                    void* work, uint32_t* counter, uint32_t work_cap, unsigned long long* safe /* kin_safe: one bit per sorted particle, a word per wave */,
                     uint32_t* force_defer /* two words per 256-particle block */, uint32_t* force_work_count /* [2] */,
                     bool cs_ready = false);
 // the chunked sweep of k_force reads up to 35 candidates past a row range when it scans global memory
 #define FS_PRED_SLACK 64
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
-                    const uint32_t* start_ref, const u64* pairs, const unsigned char* safe, float* rho,
+                    const uint32_t* start_ref, const u64* pairs, const unsigned long long* safe, float* rho,
                     float2* rho2 /* {rho, +-RN(1/rho)}: the sign is the particle's safe-operand classification */,
                     uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count /* force pass: pre-registered waves */);
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
@@ -54,7 +54,7 @@ void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots
 void launch_slab_reorder(hipStream_t st, const StepParams& P, uint32_t cap, const u64* pairs, const float2* pos_in,
                          const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s,
                          unsigned char* owned, uint32_t* cs, uint32_t* start_ref, void* work, uint32_t* counter,
-                         uint32_t work_cap, uint32_t* n_live_out, unsigned char* safe, uint32_t* force_defer,
+                         uint32_t work_cap, uint32_t* n_live_out, unsigned long long* safe, uint32_t* force_defer,
                          uint32_t* force_work_count, bool cs_ready = false);
 void launch_slab_export(hipStream_t st, const StepParams& P, uint32_t cap, const float2* pos, const float2* pred,
                         const float2* vel, const float* rho, const uint32_t* key, void* out);

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
                                                            uint32_t* __restrict__ cs, uint32_t* __restrict__ start_ref,
                                                            GapEntry* __restrict__ work, uint32_t* __restrict__ counter,
                                                            uint32_t work_cap, uint32_t* __restrict__ n_live_out,
-                                                           unsigned char* __restrict__ safe, uint32_t* __restrict__ force_defer,
+                                                           unsigned long long* __restrict__ safe, uint32_t* __restrict__ force_defer,
                                                            uint32_t* __restrict__ force_work_count) {
     const uint32_t i = blockIdx.x * SL_BLOCK + threadIdx.x;
     if (threadIdx.x == 0) {                      // the force pass's worklists of this step (same block size)
@@ -225,7 +225,10 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
     const float2 pd = predict_pos(P, p, v);
     pred_s[i] = pd;
     key_s[i] = key;
-    safe[i] = kin_safe(pd, v) ? 1 : 0;        // fs_device.h "safe operand" classification, finished by k_density
+    {   // fs_device.h "safe operand" classification (finished by k_density): one 64-bit word per wave
+        const unsigned long long sb = __builtin_amdgcn_ballot_w64(kin_safe(pd, v));   // lanes that returned above: 0
+        if ((threadIdx.x & 63u) == 0u) safe[i >> 6] = sb;
+    }
     const uint32_t cy = key / P.grid_w;
     const int32_t cxg = (int32_t)(key - cy * P.grid_w) + P.col_origin;
     owned[i] = (cxg >= (int32_t)P.own_lo && cxg < (int32_t)P.own_hi) ? 1 : 0;
@@ -354,7 +357,7 @@ void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots
 void launch_slab_reorder(hipStream_t st, const StepParams& P, uint32_t cap, const u64* pairs, const float2* pos_in,
                          const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s,
                          unsigned char* owned, uint32_t* cs, uint32_t* start_ref, void* work, uint32_t* counter,
-                         uint32_t work_cap, uint32_t* n_live_out, unsigned char* safe, uint32_t* force_defer,
+                         uint32_t work_cap, uint32_t* n_live_out, unsigned long long* safe, uint32_t* force_defer,
                          uint32_t* force_work_count, bool cs_ready) {
     if (cs_ready) {   // counting sort: table and live count already exist
         hipLaunchKernelGGL(k_slab_reorder<false>, dim3(nb(cap)), dim3(SL_BLOCK), 0, st, P, cap, pairs, pos_in, vel_in,

@@ -341,6 +341,17 @@ static int sort_mmax() {
     return m;
 }
 
+// Late stages (2^stage far beyond the distance a particle's key moves in one step) are almost entirely certified
+// no-ops: their cost is the launch count, so they take more steps per pass.
+static int sort_mmax_late() {
+    static int m = [] { const char* e = getenv("FS_SORT_MMAX_LATE"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 6 ? 6 : v); }();
+    return m;
+}
+static int sort_late_stage() {
+    static int m = [] { const char* e = getenv("FS_SORT_LATE_STAGE"); return e ? atoi(e) : 18; }();
+    return m;
+}
+
 static int sort_skip_stage() {
     static int m = [] { const char* e = getenv("FS_SORT_SKIP_STAGE"); return e ? atoi(e) : 12; }();
     return m;   // first stage whose strided passes try the no-op certificate (<0: never)
@@ -364,8 +375,9 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
                            init_stages, dirty, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
     ++launches;                                         // leaves every tile sorted and its flag cleared
     const int skip_from = sort_skip_stage();
-    const int mmax = sort_mmax();
+    const int mmax_early = sort_mmax(), mmax_late = sort_mmax_late(), late_from = sort_late_stage();
     for (uint32_t stage = SORT_LOG_T; stage < S; ++stage) {
+        const int mmax = (int)stage >= late_from ? mmax_late : mmax_early;
         // steps whose block (2 << sh) exceeds the tile: sh = stage .. SORT_LOG_T, in passes of <= mmax steps
         const int gsteps = (int)(stage - SORT_LOG_T + 1);
         const int npass = (gsteps + mmax - 1) / mmax;

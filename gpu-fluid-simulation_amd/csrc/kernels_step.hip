@@ -44,7 +44,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
                                                       uint32_t* __restrict__ key_s, uint32_t* __restrict__ cs,
                                                       uint32_t* __restrict__ start_ref, GapEntry* __restrict__ work,
                                                       uint32_t* __restrict__ counter, uint32_t work_cap,
-                                                      unsigned char* __restrict__ safe, uint32_t* __restrict__ force_defer,
+                                                      unsigned long long* __restrict__ safe, uint32_t* __restrict__ force_defer,
                                                       uint32_t* __restrict__ force_work_count) {
     const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
     if (threadIdx.x == 0) {                      // the force pass's worklists of this step (same block size and count)
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
     const float2 pd = predict_pos(P, p, v);   // same expression as the key generation in the sort -> same bits
     pred_s[i] = pd;
     key_s[i] = key;
-    safe[i] = kin_safe(pd, v) ? 1 : 0;        // fs_device.h "safe operand" classification, finished by k_density
+    {   // fs_device.h "safe operand" classification (finished by k_density): one 64-bit word per wave
+        const unsigned long long sb = __builtin_amdgcn_ballot_w64(kin_safe(pd, v));   // lanes that returned above: 0
+        if ((threadIdx.x & 63u) == 0u) safe[i >> 6] = sb;
+    }
 
     const uint32_t kc = key < P.ncell ? key : P.ncell;   // clamp for table writes only
     if (i == 0) {
@@ -151,7 +154,7 @@ template <bool TOL>
 __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2* __restrict__ pred,
                                                       const uint32_t* __restrict__ cs,
                                                       const uint32_t* __restrict__ start_ref,
-                                                      const u64* __restrict__ pairs, const unsigned char* __restrict__ safe,
+                                                      const u64* __restrict__ pairs, const unsigned long long* __restrict__ safe,
                                                       float* __restrict__ rho_out,
                                                       float2* __restrict__ rho2_out, uint32_t* __restrict__ force_defer,
                                                       uint32_t* __restrict__ force_work, uint32_t* __restrict__ force_count) {
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
     // {rho, +-RN(1/rho)}: the force pass divides by neighbours' densities; the sign carries the particle's
     // "safe operand" classification (fs_device.h) — negative sends every pair it takes part in to true divisions
     const float press = P.pressure_k * (rho - P.rest_density);  // the expression the force pass evaluates
-    const bool ok = safe[i] != 0 && rho <= FS_RCP_HI && fabsf(press) <= FS_PRESSURE_HI;
+    const bool ok = ((safe[i >> 6] >> (i & 63u)) & 1ull) != 0ull && rho <= FS_RCP_HI && fabsf(press) <= FS_PRESSURE_HI;
     const float y = __fdiv_rn(1.0f, rho);
     rho2_out[i] = make_float2(rho, ok ? y : -y);
 }
@@ -973,7 +976,7 @@ static inline uint32_t xcd_grid(uint32_t nb, uint32_t c) {      // blocks to lau
 
 void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const float2* pos_in, const float2* vel_in,
                     float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s, uint32_t* cs, uint32_t* start_ref,
-                    void* work, uint32_t* counter, uint32_t work_cap, unsigned char* safe, uint32_t* force_defer,
+                    void* work, uint32_t* counter, uint32_t work_cap, unsigned long long* safe, uint32_t* force_defer,
                     uint32_t* force_work_count, bool cs_ready) {
     if (cs_ready) {   // counting sort already produced the dense table
         hipLaunchKernelGGL(k_reorder<false>, dim3(nblk(P.n)), dim3(FS_BLOCK), 0, st, P, pairs, pos_in, vel_in, pos_s,
@@ -986,7 +989,7 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
 }
 
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
-                    const uint32_t* start_ref, const u64* pairs, const unsigned char* safe, float* rho, float2* rho2,
+                    const uint32_t* start_ref, const u64* pairs, const unsigned long long* safe, float* rho, float2* rho2,
                     uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count) {
     const uint32_t nb = nblk(P.n), grid = xcd_grid(nb, P.xcd_chunk_log2);
     if (P.fast_math == 2)
