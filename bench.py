@@ -43,7 +43,7 @@ ALG_BYTES_3D = {"predict_key": 40, "sort": 12, "reorder": 72 + 4, "density": 20,
 ALG_TOTAL_3D = 216
 
 # which kernel carries a pass (for the committed rocprofv3 counter summaries)
-PASS_KERNEL = {"force": "k_force", "density": "k_density", "sort": "k_bitonic_local<true, true>", "reorder": "k_reorder"}
+PASS_KERNEL = {"force": "k_force<", "density": "k_density", "sort": "k_bitonic_local<true, true>", "reorder": "k_reorder"}
 PASS_KERNEL_3D = {"force": "k3_force", "density": "k3_density", "sort": "k_bitonic_local", "reorder": "k3_reorder"}
 
 
@@ -297,6 +297,11 @@ def main():
                                   note="native rcp/sqrt in the force pass (<= ~1.5 ulp, inside WGSL's 2.5-ULP division "
                                        "contract for the reference shaders); not bit-exact vs the IEEE oracle"),
             "counting_sort+wgsl_ulp_math": alt_run(sort_mode=g.FS_SORT_COUNTING, math_mode=g.FS_MATH_WGSL_ULP),
+            "tolerance_math": dict(alt_run(math_mode=g.FS_MATH_TOLERANCE),
+                                   note="FS_MATH_TOLERANCE: density / force terms re-associated (FMA, one rsqrt per pair, pressure and "
+                                        "1/rho precomputed): within rtol 1e-5 / atol 1e-4*h of the IEEE oracle per step, cell keys and "
+                                        "start_indices bit-exact (north_star's float contract); reference sort"),
+            "counting_sort+tolerance_math": alt_run(sort_mode=g.FS_SORT_COUNTING, math_mode=g.FS_MATH_TOLERANCE),
         }
         # the same strict engine over later windows of the same scene: the block stays a near lattice for the
         # first ~25 steps; by step 100 it is disordered, from step ~150 the bottom of the column is dense
