@@ -574,13 +574,13 @@ __device__ __forceinline__ bool force_sweep_masks(const StepParams& P, const Row
     // plain registers: left as arrays the compiler turns the selects below into an indexed scratch load
     uint32_t la0 = la[0] << 3, la1 = la[1] << 3, la2 = la[2] << 3, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
     asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));
-    // Software-pipelined by one neighbour: the LDS read and the two gathers of neighbour k+1 are issued
-    // before the terms of neighbour k are evaluated, so a lane's own arithmetic covers their latency.
-    float2 qn = make_float2(0.0f, 0.0f), vn = qn, dn = qn;
-    bool have = false;
+    // Software-pipelined: the LDS read and the two gathers of a later neighbour are issued before the terms of
+    // neighbour k are evaluated, so a lane's own arithmetic covers their latency.  FS_PIPE_DEPTH = 1: neighbour
+    // k+1 (one slot, rotated by moves); 2: neighbours k+1 and k+2 (three slots A, B, C refilled in turn, the loop
+    // unrolled by three so no value is moved).
     uint32_t m0 = m[0], m1 = m[1], m2 = m[2];
     const wave_mask me_okm = wm(me_ok);      // the lane's own "safe operand" classification (all lanes active here)
-#define FS_FETCH_NEXT()                                                                                              \
+#define FS_FETCH(have, qn, vn, dn)                                                                                   \
     do {                                                                                                             \
         have = (m0 | m1 | m2) != 0u;                                                                                 \
         if (have) {                                                                                                  \
@@ -599,29 +599,57 @@ __device__ __forceinline__ bool force_sweep_masks(const StepParams& P, const Row
             dn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rho2) + off); /* {rho, 1/rho} */     \
         }                                                                                                            \
     } while (0)
-    FS_FETCH_NEXT();
+#define FS_PAIR(cur_valid, q0, v0, d0)                                                                               \
+    do {                                                                                                             \
+        if (cur_valid && MODE == 2) {                                                                                \
+            force_accum_tol(P, TC, me, mv, pressure, q0, v0, d0, A);                                                 \
+        } else if (cur_valid) {                                                                                      \
+            ForceTerms T0;                                                                                           \
+            if (FAST) {                                                                                              \
+                T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);                                   \
+            } else {                                                                                                 \
+                wave_mask good = 0;                                                                                  \
+                if (P.share_div) { T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good); good &= me_okm; } \
+                if (good != wm(true)) {             /* rare, wave-uniform */                                         \
+                    if (GENERAL) T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);                 \
+                    else bad = true;                                                                                 \
+                }                                                                                                    \
+            }                                                                                                        \
+            A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;                                          \
+        }                                                                                                            \
+    } while (0)
+    // measured at 16M: depth 2 is worth 2.3 % to the strict kernel (0.721 -> 0.705 ms) and COSTS the tolerance-mode
+    // kernel 5 % (0.57 -> 0.60 ms: with 24 instructions per pair the extra selects and registers outweigh the cover)
+    if constexpr (MODE == 2) {
+    float2 qn = make_float2(0.0f, 0.0f), vn = qn, dn = qn;
+    bool have = false;
+    FS_FETCH(have, qn, vn, dn);
     while (__any(have)) {
         const bool cur_valid = have;
         const float2 q0 = qn, v0 = vn, d0 = dn;
-        FS_FETCH_NEXT();
-        if (cur_valid && MODE == 2) {
-            force_accum_tol(P, TC, me, mv, pressure, q0, v0, d0, A);
-        } else if (cur_valid) {
-            ForceTerms T0;
-            if (FAST) {
-                T0 = force_terms<true>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
-            } else {
-                wave_mask good = 0;
-                if (P.share_div) { T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good); good &= me_okm; }
-                if (good != wm(true)) {             // rare, wave-uniform
-                    if (GENERAL) T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
-                    else bad = true;
-                }
-            }
-            A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
-        }
+        FS_FETCH(have, qn, vn, dn);
+        FS_PAIR(cur_valid, q0, v0, d0);
     }
-#undef FS_FETCH_NEXT
+    } else {
+    float2 qA = make_float2(0.0f, 0.0f), vA = qA, dA = qA, qB = qA, vB = qA, dB = qA, qC = qA, vC = qA, dC = qA;
+    bool hA = false, hB = false, hC = false;
+    FS_FETCH(hA, qA, vA, dA);
+    FS_FETCH(hB, qB, vB, dB);
+    FS_FETCH(hC, qC, vC, dC);
+    for (;;) {       // a slot is refilled right after its neighbour's terms: two bodies later it is consumed
+        if (!__any(hA)) break;
+        { const bool cv = hA; const float2 q0 = qA, v0 = vA, d0 = dA; FS_PAIR(cv, q0, v0, d0); }
+        FS_FETCH(hA, qA, vA, dA);
+        if (!__any(hB)) break;
+        { const bool cv = hB; const float2 q0 = qB, v0 = vB, d0 = dB; FS_PAIR(cv, q0, v0, d0); }
+        FS_FETCH(hB, qB, vB, dB);
+        if (!__any(hC)) break;
+        { const bool cv = hC; const float2 q0 = qC, v0 = vC, d0 = dC; FS_PAIR(cv, q0, v0, d0); }
+        FS_FETCH(hC, qC, vC, dC);
+    }
+    }
+#undef FS_PAIR
+#undef FS_FETCH
     // `bad` was set under the exec mask of the lanes that were evaluating the failing pair: make it the wave's
     return __any(bad);
 }
