@@ -57,8 +57,8 @@ fs_status fs_buffer_resize(fs_buffer* b, size_t new_cap, int* resized) {
     const size_t max_cap = device_max_elems(b->elem);
     if (max_cap < new_cap) {                                  // src/buffer.rs:50-55
         std::fprintf(stderr,
-                     "[%s] buffer is too large to fit in the gpu. max capacity is '%zu' requested capacity is '%zu'. "
-                     "trimming down to max capacity\n",
+                     "fluidsim: buffer '%s': %zu elements is the most this device can hold, %zu were asked for; "
+                     "clamping the resize\n",
                      b->name.c_str(), max_cap, new_cap);
         new_cap = max_cap;
     }
@@ -82,12 +82,12 @@ fs_status fs_buffer_resize(fs_buffer* b, size_t new_cap, int* resized) {
 fs_status fs_buffer_write(fs_buffer* b, size_t offset, const void* data, size_t count) {
     if (!b || (!data && count)) return FS_ERR_INVALID;
     if (offset >= b->len) {
-        if (count) std::fprintf(stderr, "buffer is too small ('%zu') to fit the data at offset '%zu'. dropping the write.\n", b->len, offset);
+        if (count) std::fprintf(stderr, "fluidsim: write at offset %zu lies past the buffer's %zu elements; nothing written\n", offset, b->len);
         return FS_OK;
     }
     if (count > b->len - offset) {                            // src/buffer.rs:71-75, offset-aware
-        std::fprintf(stderr, "buffer is too small ('%zu') to fit the data ('%zu'). trimming the data to fit the buffer.\n",
-                     b->len, count);
+        std::fprintf(stderr, "fluidsim: %zu elements do not fit behind offset %zu of a %zu-element buffer; writing the part that fits\n",
+                     count, offset, b->len);
         count = b->len - offset;
     }
     if (!count) return FS_OK;

@@ -850,13 +850,17 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
-    const uint32_t count = work_count[which];        // written earlier in the stream (k_density / the lean kernel)
-    const uint32_t* list = worklist + (which ? P.n / FS_BLOCK + 8u : 0u);
-    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-        const uint32_t blk = list[e];
-        force_block<MODE, AOS, true>(P, blk, n, defer_bits[2u * blk + which], pos_s, vel_s, pred, rho2, cs, start_ref, pairs,
-                                     tex, pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
-        __syncthreads();                             // the LDS stage is reused by the next entry
+    // which = 0 / 1: one list; which = 2: the pre-registered list, then the late one (the usual single follow-up launch)
+    for (uint32_t w = (which == 2u ? 0u : which); w <= (which == 2u ? 1u : which); ++w) {
+        const uint32_t count = work_count[w];        // written earlier in the stream (k_density / the lean kernel)
+        const uint32_t* list = worklist + (w ? P.n / FS_BLOCK + 8u : 0u);
+        for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+            const uint32_t blk = list[e];
+            force_block<MODE, AOS, true>(P, blk, n, defer_bits[2u * blk + w], pos_s, vel_s, pred, rho2, cs, start_ref, pairs,
+                                         tex, pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred,
+                                         s_red);
+            __syncthreads();                         // the LDS stage is reused by the next entry
+        }
     }
 }
 
@@ -1048,9 +1052,12 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
         (void)hipEventRecord(ev_join, side);
     }
     FS_LAUNCH_FORCE_MODE(k_force, grid, st, 0u);
-    if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
-    else FS_LAUNCH_FORCE_MODE(k_force_general, gg, st, 0u);
-    FS_LAUNCH_FORCE_MODE(k_force_general, (nb < 256u ? nb : 256u), st, 1u);
+    if (side) {
+        (void)hipStreamWaitEvent(st, ev_join, 0);
+        FS_LAUNCH_FORCE_MODE(k_force_general, (nb < 256u ? nb : 256u), st, 1u);
+    } else {
+        FS_LAUNCH_FORCE_MODE(k_force_general, gg, st, 2u);      // both lists in one follow-up launch
+    }
 #undef FS_LAUNCH_FORCE_MODE
 #undef FS_LAUNCH_FORCE
 }

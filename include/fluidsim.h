@@ -230,7 +230,10 @@ fs_status fs_build_uniform(const fs_settings* settings, const fs_tick_settings* 
  * propagation, reproduced exactly.  `field_host` may be NULL; with `sim` the result is also
  * written straight into the simulation's force field (the renderer's write_buffer,
  * src/renderer.rs:497-502), in which case (w, h) must equal settings.texture_size.  sim may be
- * NULL (then `device` selects the GPU).  Limits: h <= 1024, w < 65536. */
+ * NULL (then `device` selects the GPU).  Limits: h <= 1024, w < 65536.  The sweep is inherently sequential along
+ * x + 2y (a pixel depends on its left / upper neighbours' RESULTS), so it runs as ONE workgroup — one thread per image
+ * row, ~3 w + 2 h barrier steps — on one CU: ~1 ms at 1024^2, off the per-tick path (the reference runs it on a CPU
+ * thread per rendered frame). */
 fs_status fs_generate_force_field(fs_sim* sim, int device, const uint8_t* image, uint32_t w, uint32_t h,
                                   fs_vec2* field_host);
 
