@@ -245,39 +245,51 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
 // last(chunk) <= first(next chunk) in PHYSICAL index order then every compare-exchange of
 // the pass has key[lower index] <= key[higher index]: no swap can happen and the workgroup
 // returns after reading 2 elements per row instead of the whole 2^M x 256 block.
+// First / last key of row l (PHYSICAL order) of the 256-column chunk `chunk`, for the no-op certificate: a dirty
+// row can never certify (its "range" is everything).
+template <int M, bool FLIP>
+__device__ __forceinline__ void strided_cert_row(const u64* __restrict__ pairs, uint32_t n, uint32_t a,
+                                                 const uint32_t* __restrict__ dirty, uint32_t chunk, uint32_t l,
+                                                 uint32_t* first, uint32_t* last) {
+    constexpr int R = 1 << M;
+    const uint32_t low = a - (uint32_t)M + 1u;
+    const uint32_t mirror = (1u << a) - 1u;
+    // row l in PHYSICAL order: lower half as is; with FLIP the upper half is mirrored, so its
+    // rows appear in reverse order and each chunk is read back to front
+    const bool upper = FLIP && (l >> (M - 1));
+    const uint32_t rv = upper ? (uint32_t)(R - 1) - (l - (uint32_t)(R / 2)) : l;   // virtual row
+    const uint32_t g0 = chunk * 256u, g1 = g0 + 255u;
+    const uint32_t v0 = (((g0 >> low) << (a + 1u)) | (g0 & ((1u << low) - 1u))) | (rv << low);
+    const uint32_t v1 = (((g1 >> low) << (a + 1u)) | (g1 & ((1u << low) - 1u))) | (rv << low);
+    const uint32_t pf = upper ? (v1 ^ mirror) : v0;      // physically first / last element of the chunk
+    const uint32_t pl = upper ? (v0 ^ mirror) : v1;
+    const bool clean = dirty[pf >> SORT_LOG_T] == 0;
+    const uint32_t kf = pf < n ? (uint32_t)(pairs[pf] >> 32) : 0xFFFFFFFFu;
+    const uint32_t kl = pl < n ? (uint32_t)(pairs[pl] >> 32) : 0xFFFFFFFFu;
+    *first = clean ? kf : 0u;
+    *last = clean ? kl : 0xFFFFFFFFu;
+}
+
+template <int M, bool FLIP>
+__device__ __forceinline__ void strided_body(u64* __restrict__ pairs, uint32_t n, uint32_t a, uint32_t num_threads,
+                                             uint32_t* __restrict__ dirty, uint32_t g);
+
 template <int M, bool FLIP>
 __global__ __launch_bounds__(256) void k_bitonic_strided(u64* __restrict__ pairs, uint32_t n, uint32_t a,
                                                          uint32_t num_threads, uint32_t* __restrict__ dirty,
                                                          int try_skip) {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     constexpr int R = 1 << M;
-    const uint32_t low = a - (uint32_t)M + 1u;
-    const uint32_t mirror = (1u << a) - 1u;
     if (try_skip) {                                    // uniform branch (kernel argument)
         __shared__ uint32_t s_first[R], s_last[R];
         __shared__ int s_skip;
         const uint32_t l = threadIdx.x;
-        if (l < (uint32_t)R) {
-            // row l in PHYSICAL order: lower half as is; with FLIP the upper half is mirrored, so its
-            // rows appear in reverse order and each chunk is read back to front
-            const bool upper = FLIP && (l >> (M - 1));
-            const uint32_t rv = upper ? (uint32_t)(R - 1) - (l - (uint32_t)(R / 2)) : l;   // virtual row
-            const uint32_t g0 = blockIdx.x * 256u, g1 = g0 + 255u;
-            const uint32_t v0 = (((g0 >> low) << (a + 1u)) | (g0 & ((1u << low) - 1u))) | (rv << low);
-            const uint32_t v1 = (((g1 >> low) << (a + 1u)) | (g1 & ((1u << low) - 1u))) | (rv << low);
-            const uint32_t pf = upper ? (v1 ^ mirror) : v0;      // physically first / last element of the chunk
-            const uint32_t pl = upper ? (v0 ^ mirror) : v1;
-            const bool clean = dirty[pf >> SORT_LOG_T] == 0;
-            const uint32_t kf = pf < n ? (uint32_t)(pairs[pf] >> 32) : 0xFFFFFFFFu;
-            const uint32_t kl = pl < n ? (uint32_t)(pairs[pl] >> 32) : 0xFFFFFFFFu;
-            s_first[l] = clean ? kf : 0u;               // a dirty row can never certify:
-            s_last[l] = clean ? kl : 0xFFFFFFFFu;       //   its "range" is everything
-        }
+        if (l < (uint32_t)R) strided_cert_row<M, FLIP>(pairs, n, a, dirty, blockIdx.x, l, &s_first[l], &s_last[l]);
         __syncthreads();
         if (l == 0) {
             int ok = 1;
 #pragma unroll
-            for (int r = 0; r < R; ++r) ok &= (s_first[r] <= s_last[r]);   // dirty rows fail here? no: checked below
+            for (int r = 0; r < R; ++r) ok &= (s_first[r] <= s_last[r]);
 #pragma unroll
             for (int r = 0; r + 1 < R; ++r) ok &= (s_last[r] <= s_first[r + 1]);
             s_skip = ok;
@@ -285,6 +297,15 @@ __global__ __launch_bounds__(256) void k_bitonic_strided(u64* __restrict__ pairs
         __syncthreads();
         if (s_skip) return;
     }
+    strided_body<M, FLIP>(pairs, n, a, num_threads, dirty, g);
+}
+
+template <int M, bool FLIP>
+__device__ __forceinline__ void strided_body(u64* __restrict__ pairs, uint32_t n, uint32_t a, uint32_t num_threads,
+                                             uint32_t* __restrict__ dirty, uint32_t g) {
+    constexpr int R = 1 << M;
+    const uint32_t low = a - (uint32_t)M + 1u;
+    const uint32_t mirror = (1u << a) - 1u;
     if (g >= num_threads) return;
     const uint32_t vbase = ((g >> low) << (a + 1u)) | (g & ((1u << low) - 1u));
     u64 x[R];

@@ -844,9 +844,13 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
 //              alone with 100+ neighbours per particle) hides under the lean work;
 //   which = 1: the waves the lean kernel gave up on itself (an operand outside the proven quotient ranges) — after
 //              both, on the main stream; usually empty.
-// amdgpu_waves_per_eu(8, 8) as measured for the former single kernel (64 VGPRs, spills in the rare branches).
+// amdgpu_waves_per_eu(5, 5): 94 VGPRs, no spills, no scratch — at 8 waves (64 VGPRs, 52 spilled) even an EMPTY launch
+// cost ~17 us for the scratch set-up of its 1024 workgroups (bench window force 0.707 -> 0.690 ms).
+#ifndef FS_GENERAL_WAVES
+#define FS_GENERAL_WAVES 5
+#endif
 template <int MODE, bool AOS>
-__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_force_general(FS_FORCE_ARGS, uint32_t which) {
+__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_GENERAL_WAVES, FS_GENERAL_WAVES))) void k_force_general(FS_FORCE_ARGS, uint32_t which) {
     __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
@@ -1044,7 +1048,10 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
         else if (P.fast_math == 1) { if (aos_out) FS_LAUNCH_FORCE(K, 1, true, G, S, W); else FS_LAUNCH_FORCE(K, 1, false, G, S, W); } \
         else { if (aos_out) FS_LAUNCH_FORCE(K, 0, true, G, S, W); else FS_LAUNCH_FORCE(K, 0, false, G, S, W); }      \
     } while (0)
-    const uint32_t gg = nb < 1024u ? nb : 1024u;
+#ifndef FS_GENERAL_GRID
+#define FS_GENERAL_GRID 1024u
+#endif
+    const uint32_t gg = nb < FS_GENERAL_GRID ? nb : FS_GENERAL_GRID;
     if (side) {   // fork: the pre-registered waves on the second stream, beside the lean kernel
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
