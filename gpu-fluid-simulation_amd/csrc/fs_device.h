@@ -165,16 +165,20 @@ __device__ __forceinline__ wave_mask rcp_num_ok(float a) { return wm(fabsf(a) <=
 // div_by_rcp's numerator guards used to be evaluated per PAIR (18 compares).  Most of them follow from properties of
 // the two particles alone, so they are decided once per particle per step (k_reorder: coordinates and velocity;
 // k_density: density and pressure) and travel as the SIGN of the stored reciprocal density {rho, +-RN(1/rho)}:
-//   * a component c is "lo-safe" when c == 0 or |c| >= 2^-36.  The difference of two lo-safe floats is 0 or has
-//     magnitude >= 2^-59 (equal -> 0; one zero -> the other; else >= ulp(2^-36) = 2^-59): the numerators
-//     q - me (positions) and v_j - v_i are inside [2^-60, .] or 0 whenever both particles are safe;
+//   * a component c is "lo-safe" when c == 0 or |c| >= 2^-53.  The difference of two lo-safe floats is 0 or has
+//     magnitude >= 2^-76 (equal -> 0; one zero -> the other; else >= ulp(2^-53) = 2^-76): the numerators
+//     q - me (positions) and v_j - v_i are inside [2^-76, .] or 0 whenever both particles are safe.  2^-76 is what
+//     div_by_rcp needs with 2^-20 <= b <= 2^20: q0 = RN(a y) >= 2^-96, the residual a - b q0 is a multiple of
+//     2^(ea-47) >= 2^-123, the quotient >= 2^-96 — every intermediate normal, which is all the mantissa-pair proof
+//     assumes.  (Round 1 used 2^-60 / 2^-36 here; in the first steps of a lattice scene the x velocities are rounding
+//     noise of 1e-12..1e-9, which the old threshold sent to the true-division path by the thousand.)
 //   * |v| <= 2^59 per component  ->  |v_j - v_i| <= 2^60;
 //   * rho <= 2^20 (the reciprocal's proven range; rho >= 0.1 by construction) and |k (rho - rho0)| <= 2^39  ->
 //     |dir * kern * (P_i + P_j)/2| <= (1 + 2^-22) * h*spiky * 2^39 <= 2^60 given h * spiky <= 2^19 (checked on the host
 //     before the shared-reciprocal path is enabled).
 // What remains per pair: r2 >= 2^-40, both particles safe (two sign tests), and the lower bound of the two pressure
 // numerators (a product of three factors can be tiny without any factor being unusual).
-__device__ __forceinline__ bool lo_safe(float c) { return c == 0.0f || fabsf(c) >= 0x1p-36f; }          // NaN: false
+__device__ __forceinline__ bool lo_safe(float c) { return c == 0.0f || fabsf(c) >= 0x1p-53f; }          // NaN: false
 __device__ __forceinline__ bool kin_safe(float2 pred, float2 vel) {
     return lo_safe(pred.x) && lo_safe(pred.y) && lo_safe(vel.x) && lo_safe(vel.y) && fabsf(vel.x) <= 0x1p59f &&
            fabsf(vel.y) <= 0x1p59f;

@@ -194,6 +194,21 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
         }
         __syncthreads();
         lt_read<0, 3, false>(s, x, t);
+        {   // A tile whose keys are already in order passes through the network unchanged: every compare-exchange of
+            // an ascending network tests key[lower index] > key[higher index], which never holds (strict compare, so
+            // equal keys stay put as well).  While the fluid still moves as a lattice whole steps change no key at
+            // all, and then this kernel is key generation, one check and a store (steps 2-7, 9-11, 13-19 of the
+            // 16M dam break: 190 -> ~55 us).
+            int ok = 1;
+#pragma unroll
+            for (int r = 0; r + 1 < LT_E; ++r) ok &= (uint32_t)(x[r] >> 32) <= (uint32_t)(x[r + 1] >> 32);
+            if (t + 1u < SORT_THREADS) ok &= (uint32_t)(x[LT_E - 1] >> 32) <= (uint32_t)(s[lt_pad((t + 1u) << 4)] >> 32);
+            if (__syncthreads_and(ok)) {
+                lt_store_l3(pairs, x, base, t, n);
+                if (t == 0) dirty[blockIdx.x] = 0;
+                return;
+            }
+        }
         lt_stage_regs<0>(x);
         if (num_stages > 1) lt_stage_regs<1>(x);
         if (num_stages > 2) lt_stage_regs<2>(x);

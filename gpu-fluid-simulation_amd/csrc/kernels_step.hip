@@ -389,7 +389,7 @@ __device__ __attribute__((noinline)) void force_terms_exact_call(const StepParam
 // because the scan admitted it, and the host only enables this path for h <= 2^19: the proven sqrt range), the
 // neighbour's "safe operand" sign (fs_device.h; the lane's own is folded in by the caller), and the lower bound
 // of the two pressure numerators.
-__device__ __forceinline__ wave_mask num_lo_ok(float a) { return wm(fabsf(a) >= 0x1p-60f) | wm(a == 0.0f); }   // NaN: 0
+__device__ __forceinline__ wave_mask num_lo_ok(float a) { return wm(fabsf(a) >= 0x1p-76f) | wm(a == 0.0f); }   // NaN: 0 (fs_device.h: why 2^-76)
 __device__ __forceinline__ ForceTerms force_terms_shared(const StepParams& P, const float2 me, const float2 mv,
                                                          float pressure, const float2 q, const float2 nv,
                                                          const float2 nd /* {density, +-RN(1/density)} */, wave_mask& good) {

@@ -410,7 +410,7 @@ def test_random_configurations(fs, orc, case):
 # The force pass forms a/b from one reciprocal only inside proven ranges; everything else must take the
 # true-division body.  These scenes put numerators and denominators on both sides of every guard.
 @pytest.mark.parametrize("case", ["tiny_offsets", "tiny_velocities", "huge_velocities", "inf_velocity",
-                                  "zero_aligned", "huge_pressure", "near_zero_coordinates"])
+                                  "zero_aligned", "huge_pressure", "near_zero_coordinates", "small_operands_on_the_fast_path"])
 def test_force_quotient_guards(fs, orc, case):
     over = {}
     if case == "huge_pressure":
@@ -437,6 +437,15 @@ def test_force_quotient_guards(fs, orc, case):
         q = orc.OracleSim(st, (0.0, 0.0)).particles()
         p["position"] = q["position"]
         p["velocity"][:] = (0.25, -0.5)
+    elif case == "small_operands_on_the_fast_path":        # numerators between 2^-76 and 2^-60: exact quotients by reciprocal
+        f = np.float32
+        tiny = f(2.0 ** -53)
+        j = np.arange(n, dtype=np.float32) % 7
+        p["velocity"][:, 0] = tiny * (f(1) + j * f(2.0 ** -22))      # differences are multiples of 2^-75
+        p["velocity"][:, 1] = tiny * (f(3) - j * f(2.0 ** -21))
+        col = np.isclose(p["position"][:, 0], p["position"][np.argmin(np.abs(p["position"][:, 0])), 0])
+        k = np.nonzero(col)[0][:40]                        # one lattice column moved onto x ~ 2^-53: offsets of 2^-75 .. 2^-73
+        p["position"][k, 0] = tiny * (f(1) + (np.arange(len(k)) % 5).astype(np.float32) * f(2.0 ** -22))
     elif case == "near_zero_coordinates":                  # positions within 1e-20 of the origin: tiny but nonzero offsets
         rng = np.random.default_rng(5)
         idx = np.arange(200, 232)
