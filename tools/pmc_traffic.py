@@ -2,7 +2,7 @@
 
   rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o p --output-format csv -- python3 bench.py --no-build --steps 10 --warmup 10 --no-alt --no-cpu-baseline
   rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -o p --output-format csv -- python3 bench.py ... (same)
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <steps+warmup> profiles/rNN_X_pmc_traffic_raw.json profiles/traffic_latest.json [commit]
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <2*(steps+warmup): bench.py runs the window twice, once with per-pass events> profiles/rNN_X_pmc_traffic_raw.json profiles/traffic_latest.json [commit]
 (build first with `python __graft_entry__.py`: bench.py --no-build never compiles inside a profiled process)
 
 HBM bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024: on gfx950 FETCH_SIZE reports half of wide reads
@@ -49,7 +49,7 @@ latest = {
               "dam_break_2d_16M; HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE reports half of wide "
               "reads: MI355X_MICROARCH.md HBM section; check: k_import_aos reads 32 B x N). predict+key is fused into "
               "the sort's first kernel. Produced by tools/pmc_traffic.py from " + raw_out + ".",
-    "window": "rocprofv3 --pmc passes over a 10 + 10-step run (all 20 steps averaged), commit " + (sys.argv[6] if len(sys.argv) > 6 else "?"),
+    "window": "rocprofv3 --pmc passes over bench.py --steps 10 --warmup 10 (both of its runs of the window, all 40 steps averaged), commit " + (sys.argv[6] if len(sys.argv) > 6 else "?"),
     "bytes_per_step_by_pass": {"predict_key": 0, **{p: int(by_pass[p]) for p in ("sort", "reorder", "density", "force")}},
     "bytes_per_launch": per_launch,
     "particles": 1 << 24,
