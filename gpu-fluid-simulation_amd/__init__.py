@@ -93,6 +93,20 @@ def dam_break_2d(n):
     return settings, (float(off[0]), float(off[1])), tick
 
 
+def selftest_sort(keys, fuse_stage=-1, device=0):
+    """The engine's sort (reference network, sort.wgsl:27-51) on bare u32 keys: (sorted_keys, perm, plan).
+
+    plan = (calls that took the shifted late-stage merge, calls that took the per-stage plan); see
+    csrc/kernels_sort.hip k_late_cert.  fuse_stage: -1 default plan, 0 per-stage only, k shifted merge from stage k.
+    """
+    lib = load_library()
+    k = np.ascontiguousarray(keys, dtype=np.uint32)
+    pairs = (k.astype(np.uint64) << np.uint64(32)) | np.arange(k.shape[0], dtype=np.uint64)
+    plan = (C.c_uint32 * 2)()
+    _check(lib, lib.fs_selftest_sort(int(device), pairs.ctypes.data_as(C.c_void_p), k.shape[0], int(fuse_stage), plan))
+    return (pairs >> np.uint64(32)).astype(np.uint32), (pairs & np.uint64(0xFFFFFFFF)).astype(np.uint32), (plan[0], plan[1])
+
+
 class FluidSimulation:
     """FluidSimulation (src/simulation.rs:10-37) on one MI355X, driven through the C ABI."""
 

@@ -748,6 +748,30 @@ fs_status fs_selftest_constdiv(int device, float c, float y, float lo, float hi,
     return FS_OK;
 }
 
+/* The sort on caller-supplied pairs (tests of the late-stage plans on adversarial inputs).  Blocking. */
+fs_status fs_selftest_sort(int device, uint64_t* pairs, uint32_t n, int fuse_stage, uint32_t plan[2]) {
+    if (!pairs || n == 0 || n > (1u << 28)) return fail(FS_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(FS_ERR_DEVICE, "no HIP device");
+    FS_HIP(hipSetDevice(device));
+    unsigned long long* dp = nullptr;
+    uint32_t* dd = nullptr;
+    const size_t words = fsd::sort_tile_count(n);
+    FS_HIP(hipMalloc((void**)&dp, (size_t)n * 8));
+    hipError_t e = hipMalloc((void**)&dd, words * 4);
+    if (e == hipSuccess) e = hipMemset(dd, 0, words * 4);
+    if (e == hipSuccess) e = hipMemcpy(dp, pairs, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        fsd::launch_bitonic_sort(nullptr, dp, n, dd, nullptr, nullptr, nullptr, nullptr, fuse_stage);
+        e = hipMemcpy(pairs, dp, (size_t)n * 8, hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess && plan) e = hipMemcpy(plan, dd + fsd::sort_plan_word(n) + 1, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(dp);
+    (void)hipFree(dd);
+    if (e != hipSuccess) return fail(FS_ERR_DEVICE, hipGetErrorString(e));
+    return FS_OK;
+}
+
 /* Did the create-time proofs succeed for this handle's constants (2h^3, h^2)?  Bits 0 / 1. */
 int fs_constdiv_status(const fs_sim* s) {
     return s ? (s->div_2h3.ok ? 1 : 0) | (s->div_h2.ok ? 2 : 0) | (s->rcp_ok ? 4 : 0) | (s->sqrt_ok ? 8 : 0) : 0;

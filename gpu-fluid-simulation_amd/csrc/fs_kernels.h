@@ -69,8 +69,12 @@ size_t slab_message_bytes(uint32_t R);
 // Returns the number of kernel launches issued.
 // `dirty`: one u32 per 4096-element tile (sort_tile_count(n) entries), scratch owned by the caller.
 // keygen != nullptr: the init pass computes the pairs from pos/vel itself (predict + key fused in).
+// fuse_stage: < 0 the default late-stage plan, 0 none, k the shifted merge from stage k (see k_late_cert).
 int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty, const StepParams* keygen = nullptr,
-                        const float2* pos = nullptr, const float2* vel = nullptr, uint32_t* gap_counter = nullptr);
+                        const float2* pos = nullptr, const float2* vel = nullptr, uint32_t* gap_counter = nullptr,
+                        int fuse_stage = -1);
+// dirty[sort_plan_word(n)] : verdict of the last certificate, [+1] / [+2]: shifted-merge / per-stage plan counters
+uint32_t sort_plan_word(uint32_t n);
 uint32_t sort_tile_count(uint32_t n);
 
 // FS_SORT_COUNTING (kernels_csort.hip): fills `pairs` (stable order) and the dense table `cs`.

@@ -155,6 +155,32 @@ __device__ __forceinline__ void lt_store_l3(u64* __restrict__ pairs, const u64 (
     }
 }
 
+// Late-stage plans (see k_late_cert): `*gate` holds the certificate's verdict; a launch runs when it lies in [lo, hi].
+__device__ __forceinline__ bool gate_closed(const uint32_t* gate, uint32_t lo, uint32_t hi) {
+    if (!gate) return false;
+    const uint32_t v = *gate;
+    return v < lo || v > hi;
+}
+
+// tail of a stage >= 12: plain steps on bits 11..0 of one tile; the L1 view IS the coalesced global layout
+__device__ __forceinline__ void lt_tail(const u64* __restrict__ pairs, uint32_t n, uint32_t base, u64* s, u64 (&x)[LT_E],
+                                        uint32_t t) {
+#pragma unroll
+    for (int r = 0; r < LT_E; ++r) {
+        const uint32_t j = ((uint32_t)r << 8) | t;
+        x[r] = (base + j < n) ? pairs[base + j] : ~0ull;
+    }
+    lt_round<3, false>(x);
+    lt_write<8, 3, false>(s, x, t);
+    __syncthreads();
+    lt_read<4, 3, false>(s, x, t);
+    lt_round<3, false>(x);
+    lt_write<4, 3, false>(s, x, t);
+    lt_wave_sync();                   // L2 -> L3
+    lt_read<0, 3, false>(s, x, t);
+    lt_round<3, false>(x);
+}
+
 // `dirty[tile]` != 0 when a strided pass of the current stage swapped an element of the tile.
 // A clean tile is still sorted (it was left sorted by the previous stage's tail / the init
 // pass), so every compare of its tail is lower-index <= higher-index: a no-op.  Skipping it
@@ -167,11 +193,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
                                                                 uint32_t num_stages, uint32_t* __restrict__ dirty,
                                                                 StepParams P, const float2* __restrict__ pos,
                                                                 const float2* __restrict__ vel,
-                                                                uint32_t* __restrict__ gap_counter) {
+                                                                uint32_t* __restrict__ gap_counter,
+                                                                const uint32_t* __restrict__ gate = nullptr,
+                                                                uint32_t gate_lo = 0, uint32_t gate_hi = 0) {
     __shared__ u64 s[LT_LDS_ELEMS];
     const uint32_t base = blockIdx.x * SORT_T;
     const uint32_t t = threadIdx.x;
     if (!INIT) {
+        if (gate_closed(gate, gate_lo, gate_hi)) return;   // uniform: this launch belongs to the other late-stage plan
         if (dirty[blockIdx.x] == 0) return;            // uniform: whole tile provably unchanged
     }
     u64 x[LT_E];
@@ -222,24 +251,31 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
         if (num_stages > 10) lt_stage_high<10>(s, x, t);
         if (num_stages > 11) lt_stage_high<11>(s, x, t);
     } else {
-        // tail of a stage >= 12: plain steps on bits 11..0; the L1 view IS the coalesced global layout
-#pragma unroll
-        for (int r = 0; r < LT_E; ++r) {
-            const uint32_t j = ((uint32_t)r << 8) | t;
-            x[r] = (base + j < n) ? pairs[base + j] : ~0ull;
-        }
-        lt_round<3, false>(x);
-        lt_write<8, 3, false>(s, x, t);
-        __syncthreads();
-        lt_read<4, 3, false>(s, x, t);
-        lt_round<3, false>(x);
-        lt_write<4, 3, false>(s, x, t);
-        lt_wave_sync();                   // L2 -> L3
-        lt_read<0, 3, false>(s, x, t);
-        lt_round<3, false>(x);
+        lt_tail(pairs, n, base, s, x, t);
     }
     lt_store_l3(pairs, x, base, t, n);
     if (t == 0) dirty[blockIdx.x] = 0;                 // sorted again
+}
+
+// The tails of a late stage in compact form: few workgroups, each walking its share of the tiles.  Late stages
+// touch a few tiles only (or none at all when the shifted merge did their work), and then a launch costs what its
+// workgroups cost to dispatch: 4096 that return at once ~5 us, 512 ~2 us (16M particles).
+__global__ __launch_bounds__(SORT_THREADS) void k_bitonic_tail_walk(u64* __restrict__ pairs, uint32_t n, uint32_t tiles,
+                                                                    uint32_t* __restrict__ dirty,
+                                                                    const uint32_t* __restrict__ gate, uint32_t gate_lo,
+                                                                    uint32_t gate_hi) {
+    __shared__ u64 s[LT_LDS_ELEMS];
+    if (gate_closed(gate, gate_lo, gate_hi)) return;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        if (dirty[tile] == 0) continue;                // uniform
+        const uint32_t base = tile * SORT_T;
+        u64 x[LT_E];
+        lt_tail(pairs, n, base, s, x, t);
+        lt_store_l3(pairs, x, base, t, n);
+        if (t == 0) dirty[tile] = 0;
+        __syncthreads();                               // the LDS stage is reused
+    }
 }
 
 // M consecutive global steps of one stage in ONE pass, register-blocked: a thread owns the
@@ -278,7 +314,7 @@ __device__ __forceinline__ void strided_cert_row(const u64* __restrict__ pairs, 
     const uint32_t v1 = (((g1 >> low) << (a + 1u)) | (g1 & ((1u << low) - 1u))) | (rv << low);
     const uint32_t pf = upper ? (v1 ^ mirror) : v0;      // physically first / last element of the chunk
     const uint32_t pl = upper ? (v0 ^ mirror) : v1;
-    const bool clean = dirty[pf >> SORT_LOG_T] == 0;
+    const bool clean = pf >= n || dirty[pf >> SORT_LOG_T] == 0;   // past the end: sentinels, in order by definition
     const uint32_t kf = pf < n ? (uint32_t)(pairs[pf] >> 32) : 0xFFFFFFFFu;
     const uint32_t kl = pl < n ? (uint32_t)(pairs[pl] >> 32) : 0xFFFFFFFFu;
     *first = clean ? kf : 0u;
@@ -292,7 +328,9 @@ __device__ __forceinline__ void strided_body(u64* __restrict__ pairs, uint32_t n
 template <int M, bool FLIP>
 __global__ __launch_bounds__(256) void k_bitonic_strided(u64* __restrict__ pairs, uint32_t n, uint32_t a,
                                                          uint32_t num_threads, uint32_t* __restrict__ dirty,
-                                                         int try_skip) {
+                                                         int try_skip, const uint32_t* __restrict__ gate,
+                                                         uint32_t gate_lo, uint32_t gate_hi) {
+    if (gate_closed(gate, gate_lo, gate_hi)) return;   // uniform: this launch belongs to the other late-stage plan
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     constexpr int R = 1 << M;
     if (try_skip) {                                    // uniform branch (kernel argument)
@@ -358,14 +396,60 @@ __device__ __forceinline__ void strided_body(u64* __restrict__ pairs, uint32_t n
     }
 }
 
+// The same pass in compact form for late stages: a workgroup checks the certificates of K consecutive chunks in one
+// round of loads (K * 2^M lanes, one row each), then runs the body on the chunks that failed — usually none or one.
+// K times fewer workgroups to dispatch; exact for any input (a chunk's body touches its own elements only).
+template <int M>
+struct StridedBatch { static constexpr int R = 1 << M; static constexpr int K = (256 / R) < 8 ? (256 / R) : 8; };
+
+template <int M, bool FLIP>
+__global__ __launch_bounds__(256) void k_bitonic_strided_batch(u64* __restrict__ pairs, uint32_t n, uint32_t a,
+                                                               uint32_t num_threads, uint32_t* __restrict__ dirty,
+                                                               const uint32_t* __restrict__ gate, uint32_t gate_lo,
+                                                               uint32_t gate_hi) {
+    if (gate_closed(gate, gate_lo, gate_hi)) return;
+    constexpr int R = StridedBatch<M>::R, K = StridedBatch<M>::K;
+    __shared__ uint32_t s_first[K * R], s_last[K * R];
+    __shared__ uint32_t s_active;
+    const uint32_t nchunks = num_threads >> 8;          // whole 256-column chunks (launcher: num_threads >= 256, a power of two)
+    const uint32_t c0 = blockIdx.x * (uint32_t)K;
+    const uint32_t l = threadIdx.x;
+    if (l == 0) s_active = 0;
+    if (l < (uint32_t)(K * R) && c0 + l / (uint32_t)R < nchunks)
+        strided_cert_row<M, FLIP>(pairs, n, a, dirty, c0 + l / (uint32_t)R, l % (uint32_t)R, &s_first[l], &s_last[l]);
+    __syncthreads();
+    if (l < (uint32_t)K && c0 + l < nchunks) {
+        int ok = 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) ok &= (s_first[l * R + r] <= s_last[l * R + r]);
+#pragma unroll
+        for (int r = 0; r + 1 < R; ++r) ok &= (s_last[l * R + r] <= s_first[l * R + r + 1]);
+        if (!ok) atomicOr(&s_active, 1u << l);
+    }
+    __syncthreads();
+    uint32_t act = s_active;                            // uniform
+    while (act) {
+        const uint32_t k = (uint32_t)__builtin_ctz(act);
+        act &= act - 1u;
+        strided_body<M, FLIP>(pairs, n, a, num_threads, dirty, (c0 + k) * 256u + l);
+    }
+}
+
 template <int M>
 static void launch_strided(hipStream_t st, u64* pairs, uint32_t n, uint32_t a, bool flip, uint32_t p2,
-                           uint32_t* dirty, int try_skip) {
+                           uint32_t* dirty, int try_skip, const uint32_t* gate = nullptr, uint32_t glo = 0, uint32_t ghi = 0,
+                           bool compact = false) {
     const uint32_t threads = p2 >> M;
     const dim3 grid((threads + 255u) / 256u), block(256);
     if (threads < 256u) try_skip = 0;                  // the certificate assumes full 256-column workgroups
-    if (flip) hipLaunchKernelGGL((k_bitonic_strided<M, true>), grid, block, 0, st, pairs, n, a, threads, dirty, try_skip);
-    else hipLaunchKernelGGL((k_bitonic_strided<M, false>), grid, block, 0, st, pairs, n, a, threads, dirty, try_skip);
+    if (compact && try_skip && grid.x >= 64u) {
+        const dim3 bgrid((grid.x + StridedBatch<M>::K - 1) / StridedBatch<M>::K);
+        if (flip) hipLaunchKernelGGL((k_bitonic_strided_batch<M, true>), bgrid, block, 0, st, pairs, n, a, threads, dirty, gate, glo, ghi);
+        else hipLaunchKernelGGL((k_bitonic_strided_batch<M, false>), bgrid, block, 0, st, pairs, n, a, threads, dirty, gate, glo, ghi);
+        return;
+    }
+    if (flip) hipLaunchKernelGGL((k_bitonic_strided<M, true>), grid, block, 0, st, pairs, n, a, threads, dirty, try_skip, gate, glo, ghi);
+    else hipLaunchKernelGGL((k_bitonic_strided<M, false>), grid, block, 0, st, pairs, n, a, threads, dirty, try_skip, gate, glo, ghi);
 }
 
 static int sort_mmax() {
@@ -393,8 +477,101 @@ static int sort_skip_stage() {
     return m;   // first stage whose strided passes try the no-op certificate (<0: never)
 }
 
+// ---------------------------------------------------------------- late stages in one shifted merge
+// After stage S0-1 the array is a sequence of sorted blocks of 2^S0 = 2H elements.  Between two consecutive steps
+// of the simulation a particle's key moves by a few grid rows at most, so what the remaining stages S0 .. S-1 still
+// have to do is confined to a neighbourhood of the block boundaries m = b 2^S0.  If, for every boundary,
+//     (C2) key[m - H - 1] <= key[m]          (the part of the left block outside the window is below the right block)
+//     (C3) key[m + H]     >= key[m - 1]      (the part of the right block outside the window is above the left block)
+//     (C4) key[m - 1]     <= key[m + 2H]     (the left block is below the block after the next boundary)
+// then, with the windows W_b = [m - H, m + H):
+//   * the elements outside all windows are in non-decreasing order over the whole array and bound every window
+//     from below / above; any two windows are ordered as sets (max W_b <= min W_b+1).  By induction over the
+//     network's compare-exchanges no pair with an end outside a window, or with ends in two windows, ever swaps
+//     (key[lower index] <= key[higher index] holds for it; the compare is strict, ties never swap);
+//   * the pairs of stages >= S0 with BOTH ends in W_b are: the mirror pairs (m-1-i, m+i) of the one stage whose
+//     block centre m is (m = odd * 2^stage), and the plain steps of distance <= H/2 inside the two halves (an aligned
+//     pair of distance >= H straddles no window: m is a multiple of 2H).  The halves are sorted, so the plain
+//     steps are no-ops before that stage; its mirror + plain steps are a bitonic merge of the halves; afterwards the
+//     window is sorted and later plain steps are no-ops again.
+// Hence stages S0 .. S-1 together equal ONE merge of every window — which is stage S0-1 of the same network run on
+// the array shifted by H elements (tile aligned, H >= 4096): the kernels above, a pointer offset, 2-3 launches
+// instead of 3-4 per remaining stage.  k_late_cert evaluates (C2)-(C4) on the device and publishes the verdict;
+// the launches of both plans are in the stream and each returns at once unless the verdict names its plan, so the
+// result is the network's in every case (uploads, fast flows: the conditions fail and the per-stage plan runs).
+#define SORT_NO_PLAN 255u
+__global__ __launch_bounds__(1024) void k_late_cert(const u64* __restrict__ pairs, uint32_t n, uint32_t p2, uint32_t s0,
+                                                    uint32_t* __restrict__ gate, uint32_t* __restrict__ stat) {
+    const uint32_t H = 1u << (s0 - 1u), nb = p2 >> s0;
+    int ok = 1;
+    for (uint32_t b = 1u + threadIdx.x; b < nb; b += 1024u) {
+        const uint32_t m = b << s0;
+#define FS_KEY(p) ((p) < n ? (uint32_t)(pairs[(p)] >> 32) : 0xFFFFFFFFu)
+        const uint32_t left_max = FS_KEY(m - 1u);
+        ok &= FS_KEY(m - H - 1u) <= FS_KEY(m);
+        ok &= FS_KEY(m + H) >= left_max;
+        ok &= left_max <= FS_KEY(m + 2u * H);          // m + 2H == p2 reads as the sentinel
+#undef FS_KEY
+    }
+    const int all = __syncthreads_and(ok);
+    if (threadIdx.x == 0) {
+        *gate = all ? s0 : SORT_NO_PLAN;               // the first stage the shifted merge replaces, or none
+        if (stat) atomicAdd(&stat[all ? 0 : 1], 1u);   // diagnostics: steps that took the shifted / the per-stage plan
+    }
+}
+
+// First stage handled by the shifted merge (0: never).  Default S - 6: windows of +-2^(S-7) elements, sixteen grid rows
+// of the square dam-break scenes (a row holds 2 sqrt(n) particles).  Measured at 16M (S = 24), sort pass, ms:
+//   steps 10-110: none 0.729, 16: 0.618, 17: 0.641, 18: 0.648, 19: 0.666;  steps 150-250 (dense floor, fuller rows):
+//   none 0.802, 16 / 17: 0.82 (the certificate fails, per-stage plan + 3 idle launches), 18: 0.718, 19: 0.740.
+static int sort_fuse_stage(uint32_t S, int request) {
+    static int env = [] { const char* e = getenv("FS_SORT_FUSE_STAGE"); return e ? atoi(e) : -1; }();
+    const int want = request >= 0 ? request : env;
+    int s0 = want >= 0 ? want : (int)S - 6;
+    if (want < 0 && s0 < SORT_LOG_T + 1) s0 = SORT_LOG_T + 1;
+    if (s0 < SORT_LOG_T + 1 || s0 >= (int)S) return 0;          // H must be a whole number of tiles; something must be left
+    return s0;
+}
+
+uint32_t sort_tile_count(uint32_t n);
+uint32_t sort_plan_word(uint32_t n) { return sort_tile_count(n) - 4u; }
+
+// One stage >= SORT_LOG_T of the network on `pairs[0 .. n)`: its strided passes, then the tile tails.
+#define SORT_WALK_GRID 512u
+static int launch_stage(hipStream_t st, u64* pairs, uint32_t n, uint32_t p2, uint32_t stage, uint32_t* dirty, int mmax,
+                        int try_skip, const uint32_t* gate, uint32_t glo, uint32_t ghi, bool compact) {
+    int launches = 0;
+    const uint32_t tiles = (n + SORT_T - 1) / SORT_T;
+    // steps whose block (2 << sh) exceeds the tile: sh = stage .. SORT_LOG_T, in passes of <= mmax steps
+    const int gsteps = (int)(stage - SORT_LOG_T + 1);
+    const int npass = (gsteps + mmax - 1) / mmax;
+    uint32_t a = stage;
+    for (int ps = 0; ps < npass; ++ps) {
+        const int m = gsteps / npass + (ps < gsteps % npass ? 1 : 0);
+        const bool flip = ps == 0;
+        switch (m) {
+            case 1: launch_strided<1>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
+            case 2: launch_strided<2>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
+            case 3: launch_strided<3>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
+            case 4: launch_strided<4>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
+            case 5: launch_strided<5>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
+            default: launch_strided<6>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
+        }
+        a -= (uint32_t)m;
+        ++launches;
+    }
+    StepParams P0;
+    memset(&P0, 0, sizeof P0);
+    if (compact && tiles > SORT_WALK_GRID)
+        hipLaunchKernelGGL(k_bitonic_tail_walk, dim3(SORT_WALK_GRID), dim3(SORT_THREADS), 0, st, pairs, n, tiles, dirty, gate, glo, ghi);
+    else
+        hipLaunchKernelGGL((k_bitonic_local<false, false>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, 0u, dirty, P0,
+                           (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr, gate, glo, ghi);
+    return launches + 1;
+}
+
 int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty, const StepParams* keygen,
-                        const float2* pos, const float2* vel, uint32_t* gap_counter) {
+                        const float2* pos, const float2* vel, uint32_t* gap_counter, int fuse_stage) {
     if (n <= 1) return 0;
     uint32_t p2 = 1, S = 0;
     while (p2 < n) { p2 <<= 1; ++S; }
@@ -405,37 +582,32 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
     memset(&P0, 0, sizeof P0);
     if (keygen)
         hipLaunchKernelGGL((k_bitonic_local<true, true>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, init_stages,
-                           dirty, *keygen, pos, vel, gap_counter);
+                           dirty, *keygen, pos, vel, gap_counter, (const uint32_t*)nullptr, 0u);
     else
         hipLaunchKernelGGL((k_bitonic_local<true, false>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n,
-                           init_stages, dirty, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
+                           init_stages, dirty, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, 0u);
     ++launches;                                         // leaves every tile sorted and its flag cleared
     const int skip_from = sort_skip_stage();
     const int mmax_early = sort_mmax(), mmax_late = sort_mmax_late(), late_from = sort_late_stage();
+    const uint32_t s0 = (uint32_t)sort_fuse_stage(S, fuse_stage);
+    static const bool compact_late = [] { const char* e = getenv("FS_SORT_COMPACT"); return e ? atoi(e) != 0 : false; }();   // measured slower both gated off and active (profiles/r02_d_rejected.md)
+    uint32_t* gate = dirty + sort_plan_word(n);           // [0] verdict, [1..2] plan counters
     for (uint32_t stage = SORT_LOG_T; stage < S; ++stage) {
         const int mmax = (int)stage >= late_from ? mmax_late : mmax_early;
-        // steps whose block (2 << sh) exceeds the tile: sh = stage .. SORT_LOG_T, in passes of <= mmax steps
-        const int gsteps = (int)(stage - SORT_LOG_T + 1);
-        const int npass = (gsteps + mmax - 1) / mmax;
-        uint32_t a = stage;
-        for (int ps = 0; ps < npass; ++ps) {
-            const int m = gsteps / npass + (ps < gsteps % npass ? 1 : 0);
-            const bool flip = ps == 0;
-            const int ts = (skip_from >= 0 && (int)stage >= skip_from) ? 1 : 0;
-            switch (m) {
-                case 1: launch_strided<1>(st, pairs, n, a, flip, p2, dirty, ts); break;
-                case 2: launch_strided<2>(st, pairs, n, a, flip, p2, dirty, ts); break;
-                case 3: launch_strided<3>(st, pairs, n, a, flip, p2, dirty, ts); break;
-                case 4: launch_strided<4>(st, pairs, n, a, flip, p2, dirty, ts); break;
-                case 5: launch_strided<5>(st, pairs, n, a, flip, p2, dirty, ts); break;
-                default: launch_strided<6>(st, pairs, n, a, flip, p2, dirty, ts); break;
-            }
-            a -= (uint32_t)m;
+        const int ts = (skip_from >= 0 && (int)stage >= skip_from) ? 1 : 0;
+        if (s0 && stage == s0) {
+            // verdict, then the shifted merge (runs when the verdict is 1); stages s0 .. S-1 below run when it is 0
+            const uint32_t H = 1u << (s0 - 1u);
+            hipLaunchKernelGGL(k_late_cert, dim3(1), dim3(1024), 0, st, pairs, n, p2, s0, gate, gate + 1);
             ++launches;
+            if (n > H)
+                launches += launch_stage(st, pairs + H, n - H, p2, s0 - 1u, dirty + (H >> SORT_LOG_T), mmax_early, 1, gate, s0, s0, false);
         }
-        hipLaunchKernelGGL((k_bitonic_local<false, false>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, 0u, dirty,
-                           P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
-        ++launches;
+        // a stage at or after the verdict's is already done; in the common case these launches return at once: compact form
+        const bool gated = s0 && stage >= s0;
+        launches += launch_stage(st, pairs, n, p2, stage, dirty, mmax, ts, gated ? gate : nullptr, stage + 1u, SORT_NO_PLAN,
+                                 gated && compact_late);
     }
     return launches;
 }
@@ -443,7 +615,7 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
 uint32_t sort_tile_count(uint32_t n) {
     uint32_t p2 = 1;
     while (p2 < n) p2 <<= 1;
-    return (p2 + SORT_T - 1) / SORT_T + 1u;   // tiles of the padded array (sentinel tiles included)
+    return (p2 + SORT_T - 1) / SORT_T + 1u + 4u;   // tiles of the padded array (sentinel tiles included) + the late-stage verdict words
 }
 
 }  // namespace fsd

@@ -398,6 +398,11 @@ void fs_buffer_destroy(fs_buffer* buf);
  * = for the lean reciprocal / square root (15 = everything in use). */
 fs_status fs_selftest_constdiv(int device, float c, float y, float lo, float hi, uint32_t* mismatches);
 int fs_constdiv_status(const fs_sim* sim);
+/* The engine's sort (the reference network of sort.wgsl:27-51 on (key << 32 | index) pairs) run on `n` caller-supplied
+ * pairs, host memory, in place.  `fuse_stage` < 0: the engine's default late-stage plan; 0: per-stage launches only;
+ * k: the shifted merge from stage k (kernels_sort.hip).  plan[0] / plan[1] (may be NULL): how often the device-side
+ * certificate chose the shifted merge / the per-stage plan for this call (0, 0 when no plan was in play).  Blocking. */
+fs_status fs_selftest_sort(int device, uint64_t* pairs, uint32_t n, int fuse_stage, uint32_t plan[2]);
 
 /* ----------------------------------------------------------------- errors */
 const char* fs_last_error(void);  /* thread-local, never NULL */

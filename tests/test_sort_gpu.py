@@ -1,0 +1,105 @@
+"""The late-stage plans of the engine's sort (csrc/kernels_sort.hip: shifted merge behind a device-side certificate,
+per-stage launches otherwise) against the oracle's run of the reference network (sort.wgsl:27-51, schedule
+src/simulation.rs:323-347) on adversarial key sets: the arrangement — ties included — must be the network's whichever
+plan the certificate picks."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _moved(n, rng, reach, ties=8, frac=0.3):
+    """Sorted keys with `ties` equal keys per value, then a fraction of the elements re-keyed so that their sorted
+    position moves by up to `reach` places (what one simulation step does to the previous step's order)."""
+    k = (np.arange(n, dtype=np.int64) // ties)
+    sel = rng.random(n) < frac
+    k[sel] += rng.integers(-reach // ties, reach // ties + 1, size=int(sel.sum()))
+    return np.clip(k, 0, None).astype(np.uint32)
+
+
+def _check(fs, orc, keys, fuse, expect_plan=None):
+    want_k, want_p = orc.bitonic_keys(keys)
+    got_k, got_p, plan = fs.selftest_sort(keys, fuse_stage=fuse)
+    assert np.array_equal(got_k, want_k)
+    assert np.array_equal(got_p, want_p), f"tie arrangement differs (fuse_stage={fuse}, plan={plan})"
+    if expect_plan is not None:
+        assert plan == expect_plan, plan
+    return plan
+
+
+@pytest.mark.parametrize("n", [1 << 15, (1 << 16) + 5, 200_000, 1 << 18, (1 << 19) - 4097, 1 << 20])
+@pytest.mark.parametrize("fuse", [-1, 0, 13, 14])
+def test_small_moves_take_the_shifted_merge_and_match(fs, orc, n, fuse):
+    rng = np.random.default_rng(n + fuse)
+    keys = _moved(n, rng, reach=1500)
+    plan = _check(fs, orc, keys, fuse)
+    s = int(np.ceil(np.log2(n)))
+    s0 = fuse if fuse > 0 else (max(s - 6, 13) if fuse < 0 else 0)
+    if s0 and 13 <= s0 < s:
+        assert plan == (1, 0)            # moves of 1500 places fit the +-4096 window of stage 13 and every later one
+    else:
+        assert plan == (0, 0)
+
+
+@pytest.mark.parametrize("n", [1 << 16, 300_000, 1 << 20])
+@pytest.mark.parametrize("fuse", [-1, 13, 15])
+def test_random_keys_fail_the_certificate_and_match(fs, orc, n, fuse):
+    rng = np.random.default_rng(7 * n + fuse)
+    keys = rng.integers(0, 50_000, size=n, dtype=np.uint32)
+    plan = _check(fs, orc, keys, fuse)
+    assert plan[0] == 0
+
+
+@pytest.mark.parametrize("reach", [3000, 4000, 4200, 6000, 9000, 20000])
+def test_moves_around_the_window_size(fs, orc, reach):
+    # stage 13: windows of +-4096 places; moves below, at and above that
+    n = 1 << 18
+    rng = np.random.default_rng(reach)
+    keys = _moved(n, rng, reach=reach, ties=4, frac=0.05)
+    for fuse in (13, 14, 15):
+        _check(fs, orc, keys, fuse)
+
+
+def test_one_long_run_of_equal_keys_across_windows(fs, orc):
+    # equal keys never swap: a run of ties that covers whole windows and block boundaries must keep the network's order
+    n = 1 << 18
+    rng = np.random.default_rng(5)
+    keys = _moved(n, rng, reach=800, ties=16)
+    keys[40_000:140_000] = keys[40_000]
+    keys[140_000:] = np.maximum(keys[140_000:], keys[40_000])
+    for fuse in (13, 14, 16):
+        _check(fs, orc, keys, fuse)
+
+
+def test_sorted_and_reversed_inputs(fs, orc):
+    n = 150_000
+    keys = (np.arange(n, dtype=np.uint32) // 3)
+    assert _check(fs, orc, keys, 13) == (1, 0)
+    assert _check(fs, orc, keys[::-1].copy(), 13)[0] == 0
+
+
+def test_a_single_far_mover_forces_the_per_stage_plan(fs, orc):
+    n = 1 << 19
+    keys = (np.arange(n, dtype=np.uint32) // 8)
+    keys[1000] = keys[-1] + 5          # one element travels the whole array
+    assert _check(fs, orc, keys, 13) == (0, 1)
+    keys = (np.arange(n, dtype=np.uint32) // 8)
+    keys[n - 7] = 0                    # ... and one the other way
+    assert _check(fs, orc, keys, 14) == (0, 1)
+
+
+@pytest.mark.parametrize("kind", ["moved", "random", "far_mover"])
+def test_compact_late_launches_at_4m(fs, orc, kind):
+    # above 2M elements the gated late stages run in their compact forms (k_bitonic_tail_walk, k_bitonic_strided_batch)
+    n = (1 << 22) + 12_345
+    rng = np.random.default_rng(99)
+    if kind == "moved":
+        keys = _moved(n, rng, reach=5000)
+    elif kind == "random":
+        keys = rng.integers(0, 1 << 20, size=n, dtype=np.uint32)
+    else:
+        keys = _moved(n, rng, reach=5000)
+        keys[123] = keys.max() + 1
+    for fuse in (-1, 14, 17):
+        plan = _check(fs, orc, keys, fuse)
+        assert (plan[0] == 1) == (kind == "moved"), plan
