@@ -181,6 +181,12 @@ class FluidSimulation:
         _check(self._lib, self._lib.fs_profile_read(self._h, ms, C.byref(steps), 1 if reset else 0))
         return dict(zip(PASS_NAMES, [float(x) for x in ms])), int(steps.value)
 
+    def sort_plan(self):
+        """Diagnostics of the sort's late-stage plan (fs_sort_plan_read): dict of counts since create.  Blocking."""
+        info = _abi.SortPlanInfo()
+        _check(self._lib, self._lib.fs_sort_plan_read(self._h, C.byref(info)))
+        return {k: int(getattr(info, k)) for k, _ in _abi.SortPlanInfo._fields_}
+
     # -- data ---------------------------------------------------------------
     def uniform(self):
         u = Uniform()

@@ -174,6 +174,12 @@ class MemHandle(C.Structure):
     """fs_mem_handle (include/fluidsim.h): 80 bytes, safe to send to another process as raw bytes."""
     _fields_ = [("ipc", C.c_uint8 * 64), ("bytes", C.c_uint64), ("device", C.c_int32), ("dmabuf_fd", C.c_int32)]
 
+class SortPlanInfo(C.Structure):
+    """fs_sort_plan_info (include/fluidsim.h)."""
+    _fields_ = [("shifted", C.c_uint32), ("per_stage", C.c_uint32), ("standby_runs", C.c_uint32), ("stage", C.c_uint32),
+                ("standby_single", C.c_uint32), ("timeouts", C.c_uint32)]
+
+
 # name -> (restype, argtypes).  Every symbol include/fluidsim.h declares.
 _P = C.c_void_p
 PROTOTYPES = {
@@ -236,6 +242,7 @@ PROTOTYPES = {
     "fs3_profile_enable": (C.c_int, [_P, C.c_int]),
     "fs3_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "fs_selftest_constdiv": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint32)]),
+    "fs_sort_plan_read": (C.c_int, [C.c_void_p, C.POINTER(SortPlanInfo)]),
     "fs_selftest_sort": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]),
     "fs_constdiv_status": (C.c_int, [_P]),
     "fs_buffer_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_char_p, C.POINTER(_P)]),

@@ -69,12 +69,21 @@ size_t slab_message_bytes(uint32_t R);
 // Returns the number of kernel launches issued.
 // `dirty`: one u32 per 4096-element tile (sort_tile_count(n) entries), scratch owned by the caller.
 // keygen != nullptr: the init pass computes the pairs from pos/vel itself (predict + key fused in).
-// fuse_stage: < 0 the default late-stage plan, 0 none, k the shifted merge from stage k (see k_late_cert).
+// Late-stage plan of one sort call (kernels_sort.hip, k_late_cert).  Whatever the plan, the result is the network's.
+struct SortPlan {
+    int fuse_stage = -1;           // < 0: default stage, 0: per-stage launches only, k: the shifted merge from stage k
+    int fallback = 0;              // what stands by for a failing certificate: 0 the per-stage launches (each returns at
+                                   // once when not needed, ~5 us apiece), 1 one persistent launch (slow when it has work)
+    uint32_t* feedback = nullptr;  // host-visible words the certificate reports to (stage, verdict, fit class, seq), or none
+    uint32_t seq = 0;
+};
 int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty, const StepParams* keygen = nullptr,
                         const float2* pos = nullptr, const float2* vel = nullptr, uint32_t* gap_counter = nullptr,
-                        int fuse_stage = -1);
-// dirty[sort_plan_word(n)] : verdict of the last certificate, [+1] / [+2]: shifted-merge / per-stage plan counters
+                        const SortPlan* plan = nullptr);
+// dirty[sort_plan_word(n) ..]: [0] verdict of the last certificate, [1] / [2] shifted-merge / per-stage plan counters,
+// [3] fallback barrier, [4] fallback barrier time-outs, [5] fit class
 uint32_t sort_plan_word(uint32_t n);
+#define FS_SORT_NO_PLAN 255u
 uint32_t sort_tile_count(uint32_t n);
 
 // FS_SORT_COUNTING (kernels_csort.hip): fills `pairs` (stable order) and the dense table `cs`.

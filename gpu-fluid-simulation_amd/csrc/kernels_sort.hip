@@ -402,19 +402,15 @@ __device__ __forceinline__ void strided_body(u64* __restrict__ pairs, uint32_t n
 template <int M>
 struct StridedBatch { static constexpr int R = 1 << M; static constexpr int K = (256 / R) < 8 ? (256 / R) : 8; };
 
+// One batch: the certificates of chunks c0 .. c0+K-1 in one round of loads, then the bodies of the chunks that failed.
+// Ends with a barrier (the shared words are reusable on return).
 template <int M, bool FLIP>
-__global__ __launch_bounds__(256) void k_bitonic_strided_batch(u64* __restrict__ pairs, uint32_t n, uint32_t a,
-                                                               uint32_t num_threads, uint32_t* __restrict__ dirty,
-                                                               const uint32_t* __restrict__ gate, uint32_t gate_lo,
-                                                               uint32_t gate_hi) {
-    if (gate_closed(gate, gate_lo, gate_hi)) return;
+__device__ __forceinline__ void strided_batch(u64* pairs, uint32_t n, uint32_t a, uint32_t num_threads, uint32_t* dirty,
+                                              uint32_t c0, uint32_t* s_first, uint32_t* s_last, uint32_t* s_active) {
     constexpr int R = StridedBatch<M>::R, K = StridedBatch<M>::K;
-    __shared__ uint32_t s_first[K * R], s_last[K * R];
-    __shared__ uint32_t s_active;
     const uint32_t nchunks = num_threads >> 8;          // whole 256-column chunks (launcher: num_threads >= 256, a power of two)
-    const uint32_t c0 = blockIdx.x * (uint32_t)K;
     const uint32_t l = threadIdx.x;
-    if (l == 0) s_active = 0;
+    if (l == 0) *s_active = 0;
     if (l < (uint32_t)(K * R) && c0 + l / (uint32_t)R < nchunks)
         strided_cert_row<M, FLIP>(pairs, n, a, dirty, c0 + l / (uint32_t)R, l % (uint32_t)R, &s_first[l], &s_last[l]);
     __syncthreads();
@@ -424,15 +420,27 @@ __global__ __launch_bounds__(256) void k_bitonic_strided_batch(u64* __restrict__
         for (int r = 0; r < R; ++r) ok &= (s_first[l * R + r] <= s_last[l * R + r]);
 #pragma unroll
         for (int r = 0; r + 1 < R; ++r) ok &= (s_last[l * R + r] <= s_first[l * R + r + 1]);
-        if (!ok) atomicOr(&s_active, 1u << l);
+        if (!ok) atomicOr(s_active, 1u << l);
     }
     __syncthreads();
-    uint32_t act = s_active;                            // uniform
+    uint32_t act = *s_active;                           // uniform
     while (act) {
         const uint32_t k = (uint32_t)__builtin_ctz(act);
         act &= act - 1u;
         strided_body<M, FLIP>(pairs, n, a, num_threads, dirty, (c0 + k) * 256u + l);
     }
+    __syncthreads();
+}
+
+template <int M, bool FLIP>
+__global__ __launch_bounds__(256) void k_bitonic_strided_batch(u64* __restrict__ pairs, uint32_t n, uint32_t a,
+                                                               uint32_t num_threads, uint32_t* __restrict__ dirty,
+                                                               const uint32_t* __restrict__ gate, uint32_t gate_lo,
+                                                               uint32_t gate_hi) {
+    if (gate_closed(gate, gate_lo, gate_hi)) return;
+    __shared__ uint32_t s_first[256], s_last[256];
+    __shared__ uint32_t s_active;
+    strided_batch<M, FLIP>(pairs, n, a, num_threads, dirty, blockIdx.x * (uint32_t)StridedBatch<M>::K, s_first, s_last, &s_active);
 }
 
 template <int M>
@@ -500,23 +508,110 @@ static int sort_skip_stage() {
 // the launches of both plans are in the stream and each returns at once unless the verdict names its plan, so the
 // result is the network's in every case (uploads, fast flows: the conditions fail and the per-stage plan runs).
 #define SORT_NO_PLAN 255u
+// plan words (dirty[sort_plan_word(n) ..]): [0] verdict, [1] / [2] plan counters, [3] fallback barrier, [4] fallback
+// barrier time-outs, [5] fit class of the last certificate, [6] calls in which the stand-by kernel had work.
+// Fit class: the largest j <= 3 for which (C2), (C3) still hold with windows of H / 2^j — how much room the moves of
+// this step left; the host's choice of the next steps' stage reads it (engine.hip), never the result.
+// feedback (optional, host-visible): [1] stage, [2] verdict, [3] fit class, [4] time-outs, then [0] = seq.
 __global__ __launch_bounds__(1024) void k_late_cert(const u64* __restrict__ pairs, uint32_t n, uint32_t p2, uint32_t s0,
-                                                    uint32_t* __restrict__ gate, uint32_t* __restrict__ stat) {
+                                                    uint32_t* __restrict__ plan, uint32_t* __restrict__ feedback,
+                                                    uint32_t seq) {
     const uint32_t H = 1u << (s0 - 1u), nb = p2 >> s0;
-    int ok = 1;
+    int ok = 1, ok1 = 1, ok2 = 1, ok3 = 1;
     for (uint32_t b = 1u + threadIdx.x; b < nb; b += 1024u) {
         const uint32_t m = b << s0;
 #define FS_KEY(p) ((p) < n ? (uint32_t)(pairs[(p)] >> 32) : 0xFFFFFFFFu)
-        const uint32_t left_max = FS_KEY(m - 1u);
-        ok &= FS_KEY(m - H - 1u) <= FS_KEY(m);
+        const uint32_t left_max = FS_KEY(m - 1u), right_min = FS_KEY(m);
+        ok &= FS_KEY(m - H - 1u) <= right_min;
         ok &= FS_KEY(m + H) >= left_max;
         ok &= left_max <= FS_KEY(m + 2u * H);          // m + 2H == p2 reads as the sentinel
+        ok1 &= FS_KEY(m - (H >> 1) - 1u) <= right_min && FS_KEY(m + (H >> 1)) >= left_max;
+        ok2 &= FS_KEY(m - (H >> 2) - 1u) <= right_min && FS_KEY(m + (H >> 2)) >= left_max;
+        ok3 &= FS_KEY(m - (H >> 3) - 1u) <= right_min && FS_KEY(m + (H >> 3)) >= left_max;
 #undef FS_KEY
     }
     const int all = __syncthreads_and(ok);
+    const int a1 = __syncthreads_and(ok1), a2 = __syncthreads_and(ok2), a3 = __syncthreads_and(ok3);
     if (threadIdx.x == 0) {
-        *gate = all ? s0 : SORT_NO_PLAN;               // the first stage the shifted merge replaces, or none
-        if (stat) atomicAdd(&stat[all ? 0 : 1], 1u);   // diagnostics: steps that took the shifted / the per-stage plan
+        const uint32_t verdict = all ? s0 : SORT_NO_PLAN;      // the first stage the shifted merge replaces, or none
+        const uint32_t cls = !all ? 0u : a3 ? 3u : a2 ? 2u : a1 ? 1u : 0u;
+        plan[0] = verdict;
+        atomicAdd(&plan[all ? 1 : 2], 1u);             // diagnostics: calls that took the shifted / the per-stage plan
+        plan[3] = 0;                                    // the fallback kernel's barrier counter
+        plan[5] = cls;
+        if (feedback) {
+            feedback[1] = s0; feedback[2] = verdict; feedback[3] = cls; feedback[4] = plan[4];
+            __threadfence_system();
+            feedback[0] = seq;
+        }
+    }
+}
+
+// All workgroups of the grid have arrived `target / gridDim.x` times.  Release / acquire at agent scope around the
+// counter make the passes' plain stores visible across workgroups (other XCDs' L2 included).  The spin is bounded:
+// should the workgroups not all be resident (they are: the grid is far smaller than the chip) the kernel still ends,
+// and the time-out is counted where the host reads it.
+__device__ __forceinline__ void fallback_barrier(uint32_t* plan, uint32_t target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&plan[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&plan[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) { atomicAdd(&plan[4], 1u); break; }
+        }
+    }
+    __syncthreads();
+}
+
+template <int M>
+__device__ __forceinline__ void fallback_pass(bool flip, u64* pairs, uint32_t n, uint32_t a, uint32_t p2, uint32_t* dirty,
+                                              uint32_t* s_first, uint32_t* s_last, uint32_t* s_active) {
+    const uint32_t threads = p2 >> M, nbatch = ((threads >> 8) + StridedBatch<M>::K - 1) / StridedBatch<M>::K;
+    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+        if (flip) strided_batch<M, true>(pairs, n, a, threads, dirty, b * StridedBatch<M>::K, s_first, s_last, s_active);
+        else strided_batch<M, false>(pairs, n, a, threads, dirty, b * StridedBatch<M>::K, s_first, s_last, s_active);
+    }
+}
+
+// The per-stage plan for stages s0 .. S-1 in ONE launch, for the steps whose certificate fails although the host
+// expected it to hold (and therefore did not put the per-stage launches into the stream): a small persistent grid
+// walks the passes in order with a grid barrier between them.  Rare (the host follows the fit class with a margin,
+// engine.hip), correct for any input, several times slower than the per-stage launches when it has real work.
+__global__ __launch_bounds__(256) void k_late_fallback(u64* pairs, uint32_t n, uint32_t p2, uint32_t S, uint32_t s0,
+                                                       uint32_t* dirty, uint32_t* plan) {
+    if (plan[0] != SORT_NO_PLAN) return;               // uniform over the grid: the shifted merge did the work
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&plan[6], 1u);   // diagnostics: calls this kernel had to work in
+    __shared__ u64 s[LT_LDS_ELEMS];
+    __shared__ uint32_t s_first[256], s_last[256];
+    __shared__ uint32_t s_active;
+    const uint32_t tiles = (n + SORT_T - 1) / SORT_T, t = threadIdx.x;
+    uint32_t phase = 0;
+    for (uint32_t stage = s0; stage < S; ++stage) {
+        const int gsteps = (int)(stage - SORT_LOG_T + 1);
+        const int npass = (gsteps + 3) / 4;
+        uint32_t a = stage;
+        for (int ps = 0; ps < npass; ++ps) {
+            const int m = gsteps / npass + (ps < gsteps % npass ? 1 : 0);
+            switch (m) {
+                case 1: fallback_pass<1>(ps == 0, pairs, n, a, p2, dirty, s_first, s_last, &s_active); break;
+                case 2: fallback_pass<2>(ps == 0, pairs, n, a, p2, dirty, s_first, s_last, &s_active); break;
+                case 3: fallback_pass<3>(ps == 0, pairs, n, a, p2, dirty, s_first, s_last, &s_active); break;
+                default: fallback_pass<4>(ps == 0, pairs, n, a, p2, dirty, s_first, s_last, &s_active); break;
+            }
+            a -= (uint32_t)m;
+            fallback_barrier(plan, ++phase * gridDim.x);
+        }
+        for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+            if (dirty[tile] == 0) continue;            // uniform
+            const uint32_t base = tile * SORT_T;
+            u64 x[LT_E];
+            lt_tail(pairs, n, base, s, x, t);
+            lt_store_l3(pairs, x, base, t, n);
+            if (t == 0) dirty[tile] = 0;
+            __syncthreads();                           // the LDS stage is reused
+        }
+        fallback_barrier(plan, ++phase * gridDim.x);
     }
 }
 
@@ -534,7 +629,7 @@ static int sort_fuse_stage(uint32_t S, int request) {
 }
 
 uint32_t sort_tile_count(uint32_t n);
-uint32_t sort_plan_word(uint32_t n) { return sort_tile_count(n) - 4u; }
+uint32_t sort_plan_word(uint32_t n) { return sort_tile_count(n) - 8u; }
 
 // One stage >= SORT_LOG_T of the network on `pairs[0 .. n)`: its strided passes, then the tile tails.
 #define SORT_WALK_GRID 512u
@@ -571,7 +666,9 @@ static int launch_stage(hipStream_t st, u64* pairs, uint32_t n, uint32_t p2, uin
 }
 
 int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty, const StepParams* keygen,
-                        const float2* pos, const float2* vel, uint32_t* gap_counter, int fuse_stage) {
+                        const float2* pos, const float2* vel, uint32_t* gap_counter, const SortPlan* plan) {
+    const int fuse_stage = plan ? plan->fuse_stage : -1;
+    const bool one_fallback = plan && plan->fallback == 1;
     if (n <= 1) return 0;
     uint32_t p2 = 1, S = 0;
     while (p2 < n) { p2 <<= 1; ++S; }
@@ -592,17 +689,23 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
     const int mmax_early = sort_mmax(), mmax_late = sort_mmax_late(), late_from = sort_late_stage();
     const uint32_t s0 = (uint32_t)sort_fuse_stage(S, fuse_stage);
     static const bool compact_late = [] { const char* e = getenv("FS_SORT_COMPACT"); return e ? atoi(e) != 0 : false; }();   // measured slower both gated off and active (profiles/r02_d_rejected.md)
-    uint32_t* gate = dirty + sort_plan_word(n);           // [0] verdict, [1..2] plan counters
+    uint32_t* gate = dirty + sort_plan_word(n);           // the plan words (see k_late_cert)
     for (uint32_t stage = SORT_LOG_T; stage < S; ++stage) {
         const int mmax = (int)stage >= late_from ? mmax_late : mmax_early;
         const int ts = (skip_from >= 0 && (int)stage >= skip_from) ? 1 : 0;
         if (s0 && stage == s0) {
             // verdict, then the shifted merge (runs when the verdict is 1); stages s0 .. S-1 below run when it is 0
             const uint32_t H = 1u << (s0 - 1u);
-            hipLaunchKernelGGL(k_late_cert, dim3(1), dim3(1024), 0, st, pairs, n, p2, s0, gate, gate + 1);
+            hipLaunchKernelGGL(k_late_cert, dim3(1), dim3(1024), 0, st, pairs, n, p2, s0, gate,
+                               plan ? plan->feedback : (uint32_t*)nullptr, plan ? plan->seq : 0u);
             ++launches;
             if (n > H)
                 launches += launch_stage(st, pairs + H, n - H, p2, s0 - 1u, dirty + (H >> SORT_LOG_T), mmax_early, 1, gate, s0, s0, false);
+            if (one_fallback) {                        // everything the certificate may still ask for, in one launch
+                static const int fb_grid = [] { const char* e = getenv("FS_SORT_FALLBACK_GRID"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 256 ? 256 : v); }();
+                hipLaunchKernelGGL(k_late_fallback, dim3(fb_grid), dim3(256), 0, st, pairs, n, p2, S, s0, dirty, gate);
+                return launches + 1;
+            }
         }
         // a stage at or after the verdict's is already done; in the common case these launches return at once: compact form
         const bool gated = s0 && stage >= s0;
@@ -615,7 +718,7 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
 uint32_t sort_tile_count(uint32_t n) {
     uint32_t p2 = 1;
     while (p2 < n) p2 <<= 1;
-    return (p2 + SORT_T - 1) / SORT_T + 1u + 4u;   // tiles of the padded array (sentinel tiles included) + the late-stage verdict words
+    return (p2 + SORT_T - 1) / SORT_T + 1u + 8u;   // tiles of the padded array (sentinel tiles included) + the late-stage verdict words
 }
 
 }  // namespace fsd

@@ -400,9 +400,22 @@ fs_status fs_selftest_constdiv(int device, float c, float y, float lo, float hi,
 int fs_constdiv_status(const fs_sim* sim);
 /* The engine's sort (the reference network of sort.wgsl:27-51 on (key << 32 | index) pairs) run on `n` caller-supplied
  * pairs, host memory, in place.  `fuse_stage` < 0: the engine's default late-stage plan; 0: per-stage launches only;
- * k: the shifted merge from stage k (kernels_sort.hip).  plan[0] / plan[1] (may be NULL): how often the device-side
+ * k: the shifted merge from stage k (kernels_sort.hip); k | 0x100: the same with the single stand-by launch instead of
+ * the per-stage ones.  plan[0] / plan[1] (may be NULL): how often the device-side
  * certificate chose the shifted merge / the per-stage plan for this call (0, 0 when no plan was in play).  Blocking. */
 fs_status fs_selftest_sort(int device, uint64_t* pairs, uint32_t n, int fuse_stage, uint32_t plan[2]);
+
+/* Diagnostics of the sort's late-stage plan (csrc/kernels_sort.hip): the network's last stages run as one shifted
+ * merge when a device-side certificate allows it, as per-stage launches otherwise.  Counts since create.  Blocking. */
+typedef struct fs_sort_plan_info {
+    uint32_t shifted;        /* sorts that took the shifted merge */
+    uint32_t per_stage;      /* sorts whose certificate failed (per-stage plan: separate launches or the stand-by kernel) */
+    uint32_t standby_runs;   /* of those, done by the single stand-by kernel */
+    uint32_t stage;          /* first stage the shifted merge currently replaces (0: engine default) */
+    uint32_t standby_single; /* 1: the single stand-by launch is in use instead of the per-stage launches */
+    uint32_t timeouts;       /* stand-by grid-barrier time-outs (0 on a healthy device) */
+} fs_sort_plan_info;
+fs_status fs_sort_plan_read(fs_sim* sim, fs_sort_plan_info* out);
 
 /* ----------------------------------------------------------------- errors */
 const char* fs_last_error(void);  /* thread-local, never NULL */

@@ -103,3 +103,67 @@ def test_compact_late_launches_at_4m(fs, orc, kind):
     for fuse in (-1, 14, 17):
         plan = _check(fs, orc, keys, fuse)
         assert (plan[0] == 1) == (kind == "moved"), plan
+
+
+STANDBY = 0x100      # fs_selftest_sort: the single stand-by launch instead of the per-stage ones
+
+
+@pytest.mark.parametrize("n", [1 << 16, 300_000, (1 << 22) + 12_345])
+@pytest.mark.parametrize("kind", ["moved", "random", "far_mover", "reversed"])
+def test_standby_kernel_is_exact(fs, orc, n, kind):
+    # the persistent stand-by kernel (grid barrier between passes) must produce the network's arrangement on its own
+    rng = np.random.default_rng(n % 1000 + len(kind))
+    keys = _moved(n, rng, reach=3000)
+    if kind == "random":
+        keys = rng.integers(0, 1 << 18, size=n, dtype=np.uint32)
+    elif kind == "far_mover":
+        keys[77] = keys.max() + 3
+    elif kind == "reversed":
+        keys = keys[::-1].copy()
+    for stage in (13, 15):
+        plan = _check(fs, orc, keys, stage | STANDBY)
+        assert (plan[0] == 1) == (kind == "moved"), plan
+
+
+def _run(fs, n, steps, env, monkeypatch, disturb=None):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    st, off, tick = fs.dam_break_2d(n)
+    sim = fs.FluidSimulation(st, device=0, initial_offset=off)
+    for i in range(steps):
+        if disturb is not None:
+            disturb(sim, i)
+        sim.tick(tick)
+    out = sim.download_particles(), sim.sort_plan()
+    for k in env:
+        monkeypatch.delenv(k)
+    return out
+
+
+@pytest.mark.parametrize("n,steps", [(1 << 16, 60), (1 << 18, 40), (1 << 20, 30)])
+def test_plan_policy_never_changes_the_state(fs, monkeypatch, n, steps):
+    # whichever launch sequence the host policy picks (stage, stand-by kind), the state is the per-stage plan's
+    base, _ = _run(fs, n, steps, {"FS_SORT_POLICY": "0", "FS_SORT_FUSE_STAGE": "0"}, monkeypatch)
+    got, info = _run(fs, n, steps, {}, monkeypatch)
+    assert got.tobytes() == base.tobytes()
+    assert info["shifted"] > 0 and info["timeouts"] == 0
+    forced, info = _run(fs, n, steps, {"FS_SORT_TRUST": "1"}, monkeypatch)
+    assert forced.tobytes() == base.tobytes()
+    assert info["shifted"] + info["per_stage"] == steps and info["timeouts"] == 0
+    assert info["standby_runs"] == info["per_stage"]               # every failed certificate was served by the stand-by kernel
+
+
+def test_upload_of_a_shuffled_state_mid_run(fs, monkeypatch):
+    n = 1 << 18
+
+    def disturb(sim, i):
+        if i == 25:
+            p = sim.download_particles()
+            rng = np.random.default_rng(4)
+            sim.upload_particles(p[rng.permutation(n)])
+
+    base, _ = _run(fs, n, 40, {"FS_SORT_POLICY": "0", "FS_SORT_FUSE_STAGE": "0"}, monkeypatch, disturb)
+    got, info = _run(fs, n, 40, {}, monkeypatch, disturb)
+    assert got.tobytes() == base.tobytes() and info["timeouts"] == 0
+    forced, info = _run(fs, n, 40, {"FS_SORT_TRUST": "1"}, monkeypatch, disturb)
+    assert forced.tobytes() == base.tobytes() and info["standby_runs"] >= 1 and info["timeouts"] == 0

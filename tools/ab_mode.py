@@ -18,4 +18,4 @@ for _ in range(warm): sim.tick(tick)
 sim.sync(); sim.profile(True); sim.profile_read(True)
 ms = sim.timed_steps(tick, steps)
 p, k = sim.profile_read(True)
-print(mode, sort, f"steps {warm}-{warm+steps}", round(ms / steps, 4), {a: round(b / steps, 4) for a, b in p.items()}, flush=True)
+print(mode, sort, f"steps {warm}-{warm+steps}", round(ms / steps, 4), {a: round(b / steps, 4) for a, b in p.items()}, sim.sort_plan(), flush=True)
