@@ -15,6 +15,7 @@
 
 #include "../../include/fluidsim.h"
 #include "fs_kernels.h"
+#include "sort_policy.h"
 
 static_assert(sizeof(fs_particle) == 32, "ParticleInstance is 32 bytes (src/simulation.rs:126-135)");
 static_assert(offsetof(fs_particle, predicted_position) == 8 && offsetof(fs_particle, velocity) == 16 &&
@@ -131,22 +132,7 @@ struct fs_sim {
     fsd::ConstDiv div_2h3{}, div_h2{};   // exact constant divisions of the force pass, proven at create
     bool rcp_ok = false, sqrt_ok = false; // rcp_rn_fast / sqrt_rn_fast proven on this device at create
 
-    // Late-stage plan of the sort (kernels_sort.hip k_late_cert): the device-side certificate reports the stage it ran
-    // at, its verdict and how much room the step left ("fit class") into pinned host words; the host reads them without
-    // synchronising and picks the next steps' stage.  Only the launch sequence depends on this, never the result.
-    uint32_t* sort_fb = nullptr;    // pinned, mapped: [0] seq, [1] stage, [2] verdict, [3] fit class, [4] fallback time-outs
-    uint32_t sort_seq = 0, sort_seen = 0;
-    uint32_t sort_skip_seq = 1;     // the report of the first step after create / an upload says nothing about the flow
-    int sort_stage = 0;             // 0: not chosen yet (default stage, per-stage launches stand by)
-    int sort_roomy = 0;             // consecutive reports with the moves inside a quarter of the window
-    int sort_trusted = 0;           // consecutive passing reports at the current stage
-    bool sort_policy = true;
-    int sort_fuse_fixed = -1;       // FS_SORT_FUSE_STAGE at create: a fixed stage (0: per-stage launches only) instead of the policy
-    bool sort_force_single = false; // FS_SORT_TRUST=1 (tests): the single stand-by launch from the first step on
-    // at most FLIGHT steps are in the queue ahead of the device, so that the reports above are a few steps old
-    static const uint32_t FLIGHT = 4;
-    hipEvent_t flight[FLIGHT] = {};
-    uint64_t enqueued = 0;
+    fsd::SortPolicy sortp;          // host side of the sort's late-stage plan (sort_policy.h)
 
     // slab (multi-GPU) mode
     bool slab = false;
@@ -178,9 +164,7 @@ struct fs_sim {
         hist.release();
         for (auto& e : ev) (void)hipEventDestroy(e);
         ev.clear();
-        for (auto& e : flight) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        if (sort_fb) (void)hipHostFree(sort_fb);
-        sort_fb = nullptr;
+        sortp.release();
         if (t0) (void)hipEventDestroy(t0);
         if (t1) (void)hipEventDestroy(t1);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -374,47 +358,6 @@ fs_status drain_profile(fs_sim* s) {
     return FS_OK;
 }
 
-// Choose the late-stage plan of this step's sort from what the certificate reported for earlier steps.
-//  - a failed certificate: two stages up, the per-stage launches stand by again until reports pass;
-//  - passed, but only with the full window (fit class 0: less than 2x room): one stage up;
-//  - passed inside a quarter of the window eight reports in a row: one stage down;
-//  - the single stand-by launch replaces the per-stage ones once two reports in a row passed at the current stage.
-fs_status plan_sort(fs_sim* s, fsd::SortPlan* plan) {
-    uint32_t S = 0;
-    while ((1u << S) < s->n) ++S;
-    plan->fuse_stage = s->sort_fuse_fixed; plan->fallback = 0; plan->feedback = nullptr; plan->seq = 0;
-    if (!s->sort_policy || !s->sort_fb || S < 15) return FS_OK;
-    const volatile uint32_t* fb = s->sort_fb;
-    const uint32_t seq = fb[0];
-    if (seq != s->sort_seen) {
-        s->sort_seen = seq;
-        const int stage = (int)fb[1], cls = (int)fb[3];
-        const bool passed = fb[2] != FS_SORT_NO_PLAN;
-        if (fb[4]) return fail(FS_ERR_DEVICE, "sort: the stand-by kernel's grid barrier timed out");
-        if (s->sort_stage == 0) s->sort_stage = stage;
-        if (seq == s->sort_skip_seq) {
-            // nothing to learn
-        } else if (!passed) {
-            if (stage + 2 > s->sort_stage) s->sort_stage = stage + 2;
-            s->sort_trusted = 0; s->sort_roomy = 0;
-        } else if (cls == 0) {
-            if (stage + 1 > s->sort_stage) { s->sort_stage = stage + 1; s->sort_trusted = 0; }
-            s->sort_roomy = 0;
-        } else {
-            if (stage == s->sort_stage) s->sort_trusted += 1;
-            s->sort_roomy = (cls >= 2 && stage == s->sort_stage) ? s->sort_roomy + 1 : 0;
-            if (s->sort_roomy >= 8 && s->sort_stage > 13) { s->sort_stage -= 1; s->sort_roomy = 0; s->sort_trusted = 0; }
-        }
-        if (s->sort_stage > (int)S - 1) s->sort_stage = (int)S - 1;
-    }
-    plan->fuse_stage = s->sort_stage ? s->sort_stage : ((int)S - 8 < 13 ? 13 : (int)S - 8);
-    plan->fallback = (s->sort_stage && s->sort_trusted >= 2 && s->sort_seq - s->sort_seen <= 2 * fs_sim::FLIGHT) ? 1 : 0;
-    if (s->sort_force_single) plan->fallback = 1;
-    plan->feedback = s->sort_fb;
-    plan->seq = ++s->sort_seq;
-    return FS_OK;
-}
-
 fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     s->tick += 1;                                              // src/simulation.rs:460
     host_uniform(s->settings, *t, s->tick, &s->uniform);
@@ -430,9 +373,7 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
         ev = &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)];
     }
     if (s->n == 0) return FS_OK;
-    hipEvent_t& slot = s->flight[s->enqueued % fs_sim::FLIGHT];
-    if (slot) FS_HIP(hipEventSynchronize(slot));       // the step enqueued FLIGHT steps ago has finished
-    else FS_HIP(hipEventCreateWithFlags(&slot, hipEventDisableTiming));
+    FS_HIP(s->sortp.throttle());                       // at most SortPolicy::FLIGHT steps ahead of the device
 
     if (prof) FS_HIP(hipEventRecord(ev[0], st));
     // predict + key are fused into the first sort kernel of either mode (no separate launch)
@@ -442,8 +383,7 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
         fsd::launch_counting_sort(st, P, s->pos.p, s->vel.p, s->pairs.p, s->cs.p, s->csort.p, s->counter.p);
     } else {
         fsd::SortPlan plan;
-        fs_status r = plan_sort(s, &plan);
-        if (r != FS_OK) return r;
+        if (!s->sortp.plan(s->n, &plan)) return fail(FS_ERR_DEVICE, "sort: the stand-by kernel's grid barrier timed out");
         fsd::launch_bitonic_sort(st, s->pairs.p, s->n, s->sort_dirty.p, &P, s->pos.p, s->vel.p, s->counter.p, &plan);
     }
     if (prof) FS_HIP(hipEventRecord(ev[2], st));
@@ -459,8 +399,7 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
         FS_HIP(hipEventRecord(ev[5], st));
         s->prof_pending += 1;
     }
-    FS_HIP(hipEventRecord(s->flight[s->enqueued % fs_sim::FLIGHT], st));
-    s->enqueued += 1;
+    FS_HIP(s->sortp.step_enqueued(st));
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -546,18 +485,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     if (opts->sort_mode == FS_SORT_COUNTING) FS_TRY(s->csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
     FS_TRY(hipEventCreate(&s->t0));
     FS_TRY(hipEventCreate(&s->t1));
-    {
-        const char* e = getenv("FS_SORT_POLICY");
-        const char* fx = getenv("FS_SORT_FUSE_STAGE");
-        if (fx) s->sort_fuse_fixed = atoi(fx);
-        s->sort_policy = !(e && atoi(e) == 0) && !fx;
-        const char* tr = getenv("FS_SORT_TRUST");
-        s->sort_force_single = tr && atoi(tr) != 0;
-        if (s->sort_policy) {
-            FS_TRY(hipHostMalloc((void**)&s->sort_fb, 8 * sizeof(uint32_t), hipHostMallocMapped));
-            memset(s->sort_fb, 0, 8 * sizeof(uint32_t));
-        }
-    }
+    FS_TRY(s->sortp.init(8));
     // wgpu zero-initialises buffers: start_indices (simulation.rs:204-209), force field (:213-218)
     FS_TRY(hipMemsetAsync(s->start_ref.p, 0, s->start_ref.n * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->cs.p, 0, s->cs.n * sizeof(uint32_t), s->stream));
@@ -674,8 +602,7 @@ fs_status fs_upload_particles(fs_sim* s, const fs_particle* src, size_t n) {
     fsd::launch_import_aos(s->stream, (uint32_t)n, s->aos.p, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p);
     FS_HIP(hipStreamSynchronize(s->stream));
     s->aos_tick = 0xFFFFFFFFu;      // the live view (if any) no longer matches the state: re-materialise on demand
-    s->sort_trusted = 0;            // an arbitrary order: the per-stage launches stand by until reports pass again
-    s->sort_skip_seq = s->sort_seq + 1;
+    s->sortp.touched();             // an arbitrary order: the per-stage launches stand by until reports pass again
     return FS_OK;
 }
 
@@ -869,8 +796,8 @@ fs_status fs_sort_plan_read(fs_sim* s, fs_sort_plan_info* out) {
     const uint32_t count = s->slab ? s->capacity : s->n;
     if (count > 1) FS_HIP(hipMemcpy(w, s->sort_dirty.p + fsd::sort_plan_word(count), sizeof w, hipMemcpyDeviceToHost));
     out->shifted = w[1]; out->per_stage = w[2]; out->standby_runs = w[6]; out->timeouts = w[4];
-    out->stage = (uint32_t)s->sort_stage;
-    out->standby_single = (s->sort_stage && s->sort_trusted >= 2) ? 1u : 0u;
+    out->stage = (uint32_t)s->sortp.stage;
+    out->standby_single = (s->sortp.force_single || (s->sortp.stage && s->sortp.trusted >= 2)) ? 1u : 0u;
     return FS_OK;
 }
 
@@ -1112,7 +1039,9 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
         fsd::launch_counting_sort_pairs(st, s->capacity, P.ncell, s->pairs.p, s->cs.p, s->csort.p, s->counter.p,
                                         s->slab_counters.p);
     } else {
-        fsd::launch_bitonic_sort(st, s->pairs.p, s->capacity, s->sort_dirty.p);
+        fsd::SortPlan per_stage;               // ghosts arrive at the end of the array every step: they travel far, no shifted merge
+        per_stage.fuse_stage = 0;
+        fsd::launch_bitonic_sort(st, s->pairs.p, s->capacity, s->sort_dirty.p, nullptr, nullptr, nullptr, nullptr, &per_stage);
     }
     if (ev) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,

@@ -16,6 +16,7 @@
 
 #include "../../include/fluidsim.h"
 #include "fs_kernels.h"
+#include "sort_policy.h"
 
 static_assert(sizeof(fs3_particle) == 48, "fs3_particle is 48 bytes");
 
@@ -552,7 +553,9 @@ struct fs_sim3 {
     uint64_t steps = 0;
     fsd::ConstDiv div_2h3{}, div_h2{};
     bool share_div = false;      // all create-time proofs of the shared-denominator path succeeded
+    fsd::SortPolicy sortp;       // host side of the sort's late-stage plan (sort_policy.h)
     void release() {
+        sortp.release();
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); key.release(); cs.release();
         counter.release(); dirty.release(); pairs.release(); work.release(); aos.release();
         for (auto& e : ev) (void)hipEventDestroy(e);
@@ -608,10 +611,13 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
         ev = &s->ev[(size_t)s->pending * (FS_PASS_COUNT + 1)];
     }
     const dim3 grid((s->n + B3 - 1) / B3), block(B3);
+    H3(s->sortp.throttle());                           // at most SortPolicy::FLIGHT steps ahead of the device
     if (ev) H3(hipEventRecord(ev[0], st));
     hipLaunchKernelGGL(k3_predict_key, grid, block, 0, st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
     if (ev) H3(hipEventRecord(ev[1], st));
-    launch_bitonic_sort(st, s->pairs.p, s->n, s->dirty.p);
+    fsd::SortPlan plan;
+    if (!s->sortp.plan(s->n, &plan)) return fail3(FS_ERR_DEVICE, "sort: the stand-by kernel's grid barrier timed out");
+    launch_bitonic_sort(st, s->pairs.p, s->n, s->dirty.p, nullptr, nullptr, nullptr, nullptr, &plan);
     if (ev) H3(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k3_reorder, grid, block, 0, st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p,
                        s->pred.p, s->key.p, s->cs.p, (GapEntry*)s->work.p, s->counter.p, s->work_cap);
@@ -621,6 +627,7 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     if (ev) H3(hipEventRecord(ev[4], st));
     hipLaunchKernelGGL(k3_force, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p);
     if (ev) { H3(hipEventRecord(ev[5], st)); s->pending += 1; }
+    H3(s->sortp.step_enqueued(st));
     H3(hipGetLastError());
     return FS_OK;
 }
@@ -668,6 +675,7 @@ fs_status fs3_create(const fs3_settings* st, int device, fs_vec3 off, fs_sim3** 
     T3(hipMemsetAsync(s->cs.p, 0, s->cs.n * 4, s->stream));
     T3(hipMemsetAsync(s->counter.p, 0, 16, s->stream));
     T3(hipMemsetAsync(s->dirty.p, 0, s->dirty.n * 4, s->stream));
+    T3(s->sortp.init(5));         // a z-plane of the cube holds n^(2/3) particles: the moves are long, start at stage S - 5
     {
         std::vector<fs3_particle> host(n);
         lattice3(*st, off, host.data(), n);
@@ -746,6 +754,7 @@ fs_status fs3_upload_particles(fs_sim3* s, const fs3_particle* src, size_t n) {
     if (n) hipLaunchKernelGGL(fsd::k3_import, dim3(((uint32_t)n + B3 - 1) / B3), dim3(B3), 0, s->stream, (uint32_t)n,
                               s->aos.p, s->pos.p, s->pred.p, s->vel.p, s->key.p);
     H3(hipStreamSynchronize(s->stream));
+    s->sortp.touched();
     return FS_OK;
 }
 fs_status fs3_timed_steps(fs_sim3* s, const fs3_tick_settings* t, uint32_t steps, double* ms_total) {

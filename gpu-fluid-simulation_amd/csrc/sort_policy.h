@@ -1,0 +1,111 @@
+// sort_policy.h — host side of the sort's late-stage plan (kernels_sort.hip, k_late_cert), shared by the 2D and the
+// 3D engine.
+//
+// The device-side certificate of every sort reports the stage it ran at, its verdict and how much room the step's
+// moves left ("fit class") into pinned host words.  The host reads them WITHOUT synchronising and picks the launch
+// sequence of the next steps from them; at most FLIGHT steps are ever queued ahead of the device so that the reports
+// are a few steps old.  Only the launch sequence depends on any of this — the kernels produce the reference network's
+// arrangement whatever the plan, so a stale or wrong guess costs time, never a result.
+//   - a failed certificate: two stages up, and the per-stage launches stand by again until reports pass;
+//   - passed, but only with the full window (fit class 0: less than 2x room): one stage up;
+//   - passed inside a quarter of the window eight reports in a row: one stage down;
+//   - the single stand-by launch replaces the per-stage ones once two reports in a row passed at the current stage.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fs_kernels.h"
+
+namespace fsd {
+
+struct SortPolicy {
+    static const uint32_t FLIGHT = 4;
+    uint32_t* fb = nullptr;         // pinned, mapped: [0] seq, [1] stage, [2] verdict, [3] fit class, [4] stand-by time-outs
+    uint32_t seq = 0, seen = 0;
+    uint32_t skip_seq = 1;          // the report of the first step after create / an upload says nothing about the flow
+    int stage = 0;                  // 0: not chosen yet
+    int roomy = 0;                  // consecutive reports with the moves inside a quarter of the window
+    int trusted = 0;                // consecutive passing reports at the current stage
+    bool enabled = false;
+    bool force_single = false;      // FS_SORT_TRUST=1 (tests): the single stand-by launch from the first step on
+    int fixed_stage = -1;           // FS_SORT_FUSE_STAGE at create: a fixed stage (0: per-stage launches only), no policy
+    int start_back = 8;             // first guess: S - start_back
+    hipEvent_t flight[FLIGHT] = {};
+    uint64_t enqueued = 0;
+
+    hipError_t init(int start_back_) {
+        start_back = start_back_;
+        const char* e = getenv("FS_SORT_POLICY");
+        const char* fx = getenv("FS_SORT_FUSE_STAGE");
+        const char* tr = getenv("FS_SORT_TRUST");
+        if (fx) fixed_stage = atoi(fx);
+        force_single = tr && atoi(tr) != 0;
+        enabled = !(e && atoi(e) == 0) && !fx;
+        if (!enabled) return hipSuccess;
+        hipError_t r = hipHostMalloc((void**)&fb, 8 * sizeof(uint32_t), hipHostMallocMapped);
+        if (r == hipSuccess) memset(fb, 0, 8 * sizeof(uint32_t));
+        return r;
+    }
+    void release() {
+        for (auto& e : flight) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        if (fb) (void)hipHostFree(fb);
+        fb = nullptr;
+    }
+    // the state was replaced from outside: an arbitrary order
+    void touched() { trusted = 0; skip_seq = seq + 1; }
+
+    // Wait until the step enqueued FLIGHT steps ago has finished (call before enqueueing a step) ...
+    hipError_t throttle() {
+        hipEvent_t& slot = flight[enqueued % FLIGHT];
+        if (slot) return hipEventSynchronize(slot);
+        return hipEventCreateWithFlags(&slot, hipEventDisableTiming);
+    }
+    // ... and mark the end of the step just enqueued.
+    hipError_t step_enqueued(hipStream_t st) {
+        hipError_t r = hipEventRecord(flight[enqueued % FLIGHT], st);
+        enqueued += 1;
+        return r;
+    }
+
+    // The plan of this step's sort of n elements.  Returns false when the stand-by kernel reported a barrier time-out.
+    bool plan(uint32_t n, SortPlan* out) {
+        uint32_t S = 0;
+        while ((1u << S) < n) ++S;
+        out->fuse_stage = fixed_stage; out->fallback = 0; out->feedback = nullptr; out->seq = 0;
+        if (!enabled || !fb || S < 15) return true;
+        const volatile uint32_t* f = fb;
+        const uint32_t s = f[0];
+        if (s != seen) {
+            seen = s;
+            const int st = (int)f[1], cls = (int)f[3];
+            const bool passed = f[2] != FS_SORT_NO_PLAN;
+            if (f[4]) return false;
+            if (stage == 0) stage = st;
+            if (s == skip_seq) {
+                // nothing to learn
+            } else if (!passed) {
+                if (st + 2 > stage) stage = st + 2;
+                trusted = 0; roomy = 0;
+            } else if (cls == 0) {
+                if (st + 1 > stage) { stage = st + 1; trusted = 0; }
+                roomy = 0;
+            } else {
+                if (st == stage) trusted += 1;
+                roomy = (cls >= 2 && st == stage) ? roomy + 1 : 0;
+                if (roomy >= 8 && stage > 13) { stage -= 1; roomy = 0; trusted = 0; }
+            }
+            if (stage > (int)S - 1) stage = (int)S - 1;
+        }
+        const int first = (int)S - start_back < 13 ? 13 : (int)S - start_back;
+        out->fuse_stage = stage ? stage : first;
+        out->fallback = (stage && trusted >= 2 && seq - seen <= 2 * FLIGHT) ? 1 : 0;
+        if (force_single) out->fallback = 1;
+        out->feedback = fb;
+        out->seq = ++seq;
+        return true;
+    }
+};
+
+}  // namespace fsd

@@ -1,0 +1,13 @@
+"""Per-pass times of the 8M 3D dam break: python tools/ab_3d.py [warm] [steps]  (env FS_SORT_* selects the sort plan)"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import gpu_fluid_simulation_amd as g
+warm = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+st, off, tick = g.dam_break_3d(200 ** 3)
+sim = g.FluidSimulation3D(st, device=0, initial_offset=off)
+for _ in range(warm): sim.tick(tick)
+sim.sync(); sim.profile(True); sim.profile_read(True)
+ms = sim.timed_steps(tick, steps)
+p, k = sim.profile_read(True)
+print("3d", f"steps {warm}-{warm+steps}", round(ms / steps, 4), {a: round(b / steps, 4) for a, b in p.items()}, flush=True)
