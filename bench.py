@@ -233,6 +233,8 @@ def main():
     ms = sim.timed_steps(tick, args.steps)
     sim.sync()
     t_wall = (time.perf_counter() - t_wall) * 1e3
+    # which late-stage plan the sorts of this handle took (csrc/kernels_sort.hip; the result does not depend on it)
+    sort_plan = sim.sort_plan() if (not is3d and args.sort == "bitonic") else None
     sim.close()
     ms_per_step = ms / args.steps
     value = n / (ms_per_step * 1e-3) / 1e6            # M particle-steps/s
@@ -242,7 +244,7 @@ def main():
     ms_profiled, per_pass = run_window(make_sim, tick, args.warmup, args.steps, n, alg_bytes)
     # the dominant KERNEL: a pass's time x the share its largest kernel has of it (the sort pass is ~37 launches, the
     # largest ~27 % of it; the force pass is the lean kernel + the general one, profiles/r02_f_kernel_stats.csv)
-    share = {"sort": 0.27, "force": 0.94, "density": 1.0, "reorder": 0.97, "predict_key": 1.0}
+    share = {"sort": 0.33, "force": 0.94, "density": 1.0, "reorder": 0.97, "predict_key": 1.0}
     dom = max(per_pass, key=lambda k: per_pass[k]["ms"] * share.get(k, 1.0))
 
     traffic, traffic_src = args.pmc_traffic, "--pmc-traffic argument (separate rocprofv3 --pmc run of this command)"
@@ -286,6 +288,10 @@ def main():
         "host_wall_ms_per_step": round(t_wall / args.steps, 4),
         "roofline": roofline,
     }
+    if sort_plan is not None:
+        out["config"]["sort_plan"] = dict(sort_plan, note="sorts of the warm-up + timed steps by late-stage plan: 'shifted' = one "
+                                          "shifted merge replaced stages >= 'stage' (device-side certificate held), 'per_stage' = it "
+                                          "failed and the per-stage passes ran; bit-identical arrangement either way")
     if not is3d and args.sort == "bitonic" and not args.no_alt:
         # extras (NOT the headline): the same scene and protocol in the engine's opt-in modes
         def alt_run(**kw):
