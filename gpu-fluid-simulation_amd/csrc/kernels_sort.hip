@@ -577,7 +577,8 @@ __device__ __forceinline__ void fallback_pass(bool flip, u64* pairs, uint32_t n,
 // The per-stage plan for stages s0 .. S-1 in ONE launch, for the steps whose certificate fails although the host
 // expected it to hold (and therefore did not put the per-stage launches into the stream): a small persistent grid
 // walks the passes in order with a grid barrier between them.  Rare (the host follows the fit class with a margin,
-// engine.hip), correct for any input, several times slower than the per-stage launches when it has real work.
+// sort_policy.h), correct for any input, several times slower than the per-stage launches when it has real work
+// (16M: ~3.5 ms against 0.25 ms of per-stage launches: every barrier is an L2 write-back and invalidate).
 __global__ __launch_bounds__(256) void k_late_fallback(u64* pairs, uint32_t n, uint32_t p2, uint32_t S, uint32_t s0,
                                                        uint32_t* dirty, uint32_t* plan) {
     if (plan[0] != SORT_NO_PLAN) return;               // uniform over the grid: the shifted merge did the work
@@ -702,7 +703,14 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
             if (n > H)
                 launches += launch_stage(st, pairs + H, n - H, p2, s0 - 1u, dirty + (H >> SORT_LOG_T), mmax_early, 1, gate, s0, s0, false);
             if (one_fallback) {                        // everything the certificate may still ask for, in one launch
-                static const int fb_grid = [] { const char* e = getenv("FS_SORT_FALLBACK_GRID"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 256 ? 256 : v); }();
+                // one workgroup per CU at most: all of them resident whatever else the kernel shares the chip with
+                static const int fb_grid = [] {
+                    const char* e = getenv("FS_SORT_FALLBACK_GRID");
+                    int dev = 0, cus = 64;
+                    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                    int v = e ? atoi(e) : (cus > 128 ? 128 : cus);   // 16M, 16 working calls in 110: 64: sort 1.08 ms avg, 128: 1.01, 256: 1.12
+                    return v < 1 ? 1 : (v > 256 ? 256 : v);
+                }();
                 hipLaunchKernelGGL(k_late_fallback, dim3(fb_grid), dim3(256), 0, st, pairs, n, p2, S, s0, dirty, gate);
                 return launches + 1;
             }

@@ -73,7 +73,7 @@ struct SortPolicy {
     bool plan(uint32_t n, SortPlan* out) {
         uint32_t S = 0;
         while ((1u << S) < n) ++S;
-        out->fuse_stage = fixed_stage; out->fallback = 0; out->feedback = nullptr; out->seq = 0;
+        out->fuse_stage = fixed_stage; out->fallback = (force_single && fixed_stage > 0) ? 1 : 0; out->feedback = nullptr; out->seq = 0;
         if (!enabled || !fb || S < 15) return true;
         const volatile uint32_t* f = fb;
         const uint32_t s = f[0];
