@@ -257,6 +257,56 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
     if (t == 0) dirty[blockIdx.x] = 0;                 // sorted again
 }
 
+// The twelve plain steps of a tail on a tile already in registers (L1 layout as held by thread `t1`: the caller may hold
+// the tile mirrored, see k_bitonic_stage12), ending in the L3 layout of the real thread.
+__device__ __forceinline__ void lt_tail_regs(u64* s, u64 (&x)[LT_E], uint32_t t1, uint32_t t) {
+    lt_round<3, false>(x);
+    lt_write<8, 3, false>(s, x, t1);
+    __syncthreads();
+    lt_read<4, 3, false>(s, x, t);
+    lt_round<3, false>(x);
+    lt_write<4, 3, false>(s, x, t);
+    lt_wave_sync();                   // L2 -> L3
+    lt_read<0, 3, false>(s, x, t);
+    lt_round<3, false>(x);
+}
+
+// Stage 12 in ONE kernel: its only global step is the mirror step between the two tiles of an 8192-block, so a
+// workgroup takes both tiles: A in the L1 layout, B read back to front (thread t holds B[4095 - (r << 8 | t)], still
+// a coalesced load) — the mirror partners then sit in the same register slot of the same thread.  After the
+// compare-exchanges A's tail runs from the registers; B's registers, renamed r -> 15 - r, ARE the L1 layout of thread
+// 255 - t, so its tail only writes its first LDS round with that thread id.  Saves the strided pass (one read + write of
+// the pair array) and a launch.  Certificate: last(A) <= first(B) (both tiles are sorted on entry) => no compare of the
+// stage can swap; otherwise the pair (last(A), first(B)) itself swaps and both tails are needed.
+__global__ __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bitonic_stage12(u64* __restrict__ pairs, uint32_t n) {
+    __shared__ u64 s[LT_LDS_ELEMS];
+    const uint32_t t = threadIdx.x;
+    const uint32_t base_a = blockIdx.x * (2u * SORT_T), base_b = base_a + SORT_T;
+    if (base_b >= n) return;                           // B holds sentinels only: nothing can swap
+    {
+        const uint32_t last_a = (uint32_t)(pairs[base_b - 1u] >> 32), first_b = (uint32_t)(pairs[base_b] >> 32);
+        if (last_a <= first_b) return;                 // uniform
+    }
+    u64 xa[LT_E], xb[LT_E];
+#pragma unroll
+    for (int r = 0; r < LT_E; ++r) {
+        const uint32_t j = ((uint32_t)r << 8) | t;
+        xa[r] = pairs[base_a + j];                     // base_b < n: A is complete
+        const uint32_t pb = base_b + (SORT_T - 1u - j);
+        xb[r] = pb < n ? pairs[pb] : ~0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < LT_E; ++r) lt_cx(xa[r], xb[r]);            // A[j] vs B[4095 - j]: the stage's mirror step
+    lt_tail_regs(s, xa, t, t);
+    lt_store_l3(pairs, xa, base_a, t, n);
+    u64 xn[LT_E];
+#pragma unroll
+    for (int r = 0; r < LT_E; ++r) xn[r] = xb[LT_E - 1 - r];        // natural order of thread 255 - t
+    __syncthreads();                                   // A's last LDS reads are done
+    lt_tail_regs(s, xn, SORT_THREADS - 1u - t, t);
+    lt_store_l3(pairs, xn, base_b, t, n);
+}
+
 // The tails of a late stage in compact form: few workgroups, each walking its share of the tiles.  Late stages
 // touch a few tiles only (or none at all when the shifted merge did their work), and then a launch costs what its
 // workgroups cost to dispatch: 4096 that return at once ~5 us, 512 ~2 us (16M particles).
@@ -689,6 +739,7 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
     const int skip_from = sort_skip_stage();
     const int mmax_early = sort_mmax(), mmax_late = sort_mmax_late(), late_from = sort_late_stage();
     const uint32_t s0 = (uint32_t)sort_fuse_stage(S, fuse_stage);
+    static const bool fused12 = [] { const char* e = getenv("FS_SORT_FUSED12"); return e ? atoi(e) != 0 : true; }();
     static const bool compact_late = [] { const char* e = getenv("FS_SORT_COMPACT"); return e ? atoi(e) != 0 : false; }();   // measured slower both gated off and active (profiles/r02_d_rejected.md)
     uint32_t* gate = dirty + sort_plan_word(n);           // the plan words (see k_late_cert)
     for (uint32_t stage = SORT_LOG_T; stage < S; ++stage) {
@@ -717,6 +768,11 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
         }
         // a stage at or after the verdict's is already done; in the common case these launches return at once: compact form
         const bool gated = s0 && stage >= s0;
+        if (stage == SORT_LOG_T && fused12) {          // (never gated: s0 > SORT_LOG_T)
+            hipLaunchKernelGGL(k_bitonic_stage12, dim3((tiles + 1u) / 2u), dim3(SORT_THREADS), 0, st, pairs, n);
+            ++launches;
+            continue;
+        }
         launches += launch_stage(st, pairs, n, p2, stage, dirty, mmax, ts, gated ? gate : nullptr, stage + 1u, SORT_NO_PLAN,
                                  gated && compact_late);
     }
