@@ -307,27 +307,6 @@ __global__ __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     lt_store_l3(pairs, xn, base_b, t, n);
 }
 
-// The tails of a late stage in compact form: few workgroups, each walking its share of the tiles.  Late stages
-// touch a few tiles only (or none at all when the shifted merge did their work), and then a launch costs what its
-// workgroups cost to dispatch: 4096 that return at once ~5 us, 512 ~2 us (16M particles).
-__global__ __launch_bounds__(SORT_THREADS) void k_bitonic_tail_walk(u64* __restrict__ pairs, uint32_t n, uint32_t tiles,
-                                                                    uint32_t* __restrict__ dirty,
-                                                                    const uint32_t* __restrict__ gate, uint32_t gate_lo,
-                                                                    uint32_t gate_hi) {
-    __shared__ u64 s[LT_LDS_ELEMS];
-    if (gate_closed(gate, gate_lo, gate_hi)) return;
-    const uint32_t t = threadIdx.x;
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        if (dirty[tile] == 0) continue;                // uniform
-        const uint32_t base = tile * SORT_T;
-        u64 x[LT_E];
-        lt_tail(pairs, n, base, s, x, t);
-        lt_store_l3(pairs, x, base, t, n);
-        if (t == 0) dirty[tile] = 0;
-        __syncthreads();                               // the LDS stage is reused
-    }
-}
-
 // M consecutive global steps of one stage in ONE pass, register-blocked: a thread owns the
 // 2^M elements whose indices differ only in bits [a-M+1, a] (a = stage - first step), loads
 // them (each load is a coalesced 512-B wave segment: consecutive lanes = consecutive
@@ -446,9 +425,10 @@ __device__ __forceinline__ void strided_body(u64* __restrict__ pairs, uint32_t n
     }
 }
 
-// The same pass in compact form for late stages: a workgroup checks the certificates of K consecutive chunks in one
-// round of loads (K * 2^M lanes, one row each), then runs the body on the chunks that failed — usually none or one.
-// K times fewer workgroups to dispatch; exact for any input (a chunk's body touches its own elements only).
+// The same pass in batch form, for the persistent stand-by kernel (k_late_fallback): a workgroup checks the
+// certificates of K consecutive chunks in one round of loads (K * 2^M lanes, one row each), then runs the body on the
+// chunks that failed.  Exact for any input (a chunk's body touches its own elements only).  As launches of their own
+// the batch form and a tile-walking tail were measured slower than the plain kernels (profiles/r02_d_rejected.md).
 template <int M>
 struct StridedBatch { static constexpr int R = 1 << M; static constexpr int K = (256 / R) < 8 ? (256 / R) : 8; };
 
@@ -482,30 +462,12 @@ __device__ __forceinline__ void strided_batch(u64* pairs, uint32_t n, uint32_t a
     __syncthreads();
 }
 
-template <int M, bool FLIP>
-__global__ __launch_bounds__(256) void k_bitonic_strided_batch(u64* __restrict__ pairs, uint32_t n, uint32_t a,
-                                                               uint32_t num_threads, uint32_t* __restrict__ dirty,
-                                                               const uint32_t* __restrict__ gate, uint32_t gate_lo,
-                                                               uint32_t gate_hi) {
-    if (gate_closed(gate, gate_lo, gate_hi)) return;
-    __shared__ uint32_t s_first[256], s_last[256];
-    __shared__ uint32_t s_active;
-    strided_batch<M, FLIP>(pairs, n, a, num_threads, dirty, blockIdx.x * (uint32_t)StridedBatch<M>::K, s_first, s_last, &s_active);
-}
-
 template <int M>
 static void launch_strided(hipStream_t st, u64* pairs, uint32_t n, uint32_t a, bool flip, uint32_t p2,
-                           uint32_t* dirty, int try_skip, const uint32_t* gate = nullptr, uint32_t glo = 0, uint32_t ghi = 0,
-                           bool compact = false) {
+                           uint32_t* dirty, int try_skip, const uint32_t* gate = nullptr, uint32_t glo = 0, uint32_t ghi = 0) {
     const uint32_t threads = p2 >> M;
     const dim3 grid((threads + 255u) / 256u), block(256);
     if (threads < 256u) try_skip = 0;                  // the certificate assumes full 256-column workgroups
-    if (compact && try_skip && grid.x >= 64u) {
-        const dim3 bgrid((grid.x + StridedBatch<M>::K - 1) / StridedBatch<M>::K);
-        if (flip) hipLaunchKernelGGL((k_bitonic_strided_batch<M, true>), bgrid, block, 0, st, pairs, n, a, threads, dirty, gate, glo, ghi);
-        else hipLaunchKernelGGL((k_bitonic_strided_batch<M, false>), bgrid, block, 0, st, pairs, n, a, threads, dirty, gate, glo, ghi);
-        return;
-    }
     if (flip) hipLaunchKernelGGL((k_bitonic_strided<M, true>), grid, block, 0, st, pairs, n, a, threads, dirty, try_skip, gate, glo, ghi);
     else hipLaunchKernelGGL((k_bitonic_strided<M, false>), grid, block, 0, st, pairs, n, a, threads, dirty, try_skip, gate, glo, ghi);
 }
@@ -683,9 +645,8 @@ uint32_t sort_tile_count(uint32_t n);
 uint32_t sort_plan_word(uint32_t n) { return sort_tile_count(n) - 8u; }
 
 // One stage >= SORT_LOG_T of the network on `pairs[0 .. n)`: its strided passes, then the tile tails.
-#define SORT_WALK_GRID 512u
 static int launch_stage(hipStream_t st, u64* pairs, uint32_t n, uint32_t p2, uint32_t stage, uint32_t* dirty, int mmax,
-                        int try_skip, const uint32_t* gate, uint32_t glo, uint32_t ghi, bool compact) {
+                        int try_skip, const uint32_t* gate, uint32_t glo, uint32_t ghi) {
     int launches = 0;
     const uint32_t tiles = (n + SORT_T - 1) / SORT_T;
     // steps whose block (2 << sh) exceeds the tile: sh = stage .. SORT_LOG_T, in passes of <= mmax steps
@@ -696,23 +657,20 @@ static int launch_stage(hipStream_t st, u64* pairs, uint32_t n, uint32_t p2, uin
         const int m = gsteps / npass + (ps < gsteps % npass ? 1 : 0);
         const bool flip = ps == 0;
         switch (m) {
-            case 1: launch_strided<1>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
-            case 2: launch_strided<2>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
-            case 3: launch_strided<3>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
-            case 4: launch_strided<4>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
-            case 5: launch_strided<5>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
-            default: launch_strided<6>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi, compact); break;
+            case 1: launch_strided<1>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi); break;
+            case 2: launch_strided<2>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi); break;
+            case 3: launch_strided<3>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi); break;
+            case 4: launch_strided<4>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi); break;
+            case 5: launch_strided<5>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi); break;
+            default: launch_strided<6>(st, pairs, n, a, flip, p2, dirty, try_skip, gate, glo, ghi); break;
         }
         a -= (uint32_t)m;
         ++launches;
     }
     StepParams P0;
     memset(&P0, 0, sizeof P0);
-    if (compact && tiles > SORT_WALK_GRID)
-        hipLaunchKernelGGL(k_bitonic_tail_walk, dim3(SORT_WALK_GRID), dim3(SORT_THREADS), 0, st, pairs, n, tiles, dirty, gate, glo, ghi);
-    else
-        hipLaunchKernelGGL((k_bitonic_local<false, false>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, 0u, dirty, P0,
-                           (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr, gate, glo, ghi);
+    hipLaunchKernelGGL((k_bitonic_local<false, false>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, 0u, dirty, P0,
+                       (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr, gate, glo, ghi);
     return launches + 1;
 }
 
@@ -740,7 +698,6 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
     const int mmax_early = sort_mmax(), mmax_late = sort_mmax_late(), late_from = sort_late_stage();
     const uint32_t s0 = (uint32_t)sort_fuse_stage(S, fuse_stage);
     static const bool fused12 = [] { const char* e = getenv("FS_SORT_FUSED12"); return e ? atoi(e) != 0 : true; }();
-    static const bool compact_late = [] { const char* e = getenv("FS_SORT_COMPACT"); return e ? atoi(e) != 0 : false; }();   // measured slower both gated off and active (profiles/r02_d_rejected.md)
     uint32_t* gate = dirty + sort_plan_word(n);           // the plan words (see k_late_cert)
     for (uint32_t stage = SORT_LOG_T; stage < S; ++stage) {
         const int mmax = (int)stage >= late_from ? mmax_late : mmax_early;
@@ -752,7 +709,10 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
                                plan ? plan->feedback : (uint32_t*)nullptr, plan ? plan->seq : 0u);
             ++launches;
             if (n > H)
-                launches += launch_stage(st, pairs + H, n - H, p2, s0 - 1u, dirty + (H >> SORT_LOG_T), mmax_early, 1, gate, s0, s0, false);
+                {
+                    static const int mm = [] { const char* e = getenv("FS_SORT_MMAX_SHIFTED"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 6 ? 6 : v); }();
+                    launches += launch_stage(st, pairs + H, n - H, p2, s0 - 1u, dirty + (H >> SORT_LOG_T), mm, 1, gate, s0, s0);
+                }
             if (one_fallback) {                        // everything the certificate may still ask for, in one launch
                 // one workgroup per CU at most: all of them resident whatever else the kernel shares the chip with
                 static const int fb_grid = [] {
@@ -766,15 +726,14 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
                 return launches + 1;
             }
         }
-        // a stage at or after the verdict's is already done; in the common case these launches return at once: compact form
+        // a stage at or after the verdict's is already done: these launches then return at once (~5 us each)
         const bool gated = s0 && stage >= s0;
         if (stage == SORT_LOG_T && fused12) {          // (never gated: s0 > SORT_LOG_T)
             hipLaunchKernelGGL(k_bitonic_stage12, dim3((tiles + 1u) / 2u), dim3(SORT_THREADS), 0, st, pairs, n);
             ++launches;
             continue;
         }
-        launches += launch_stage(st, pairs, n, p2, stage, dirty, mmax, ts, gated ? gate : nullptr, stage + 1u, SORT_NO_PLAN,
-                                 gated && compact_late);
+        launches += launch_stage(st, pairs, n, p2, stage, dirty, mmax, ts, gated ? gate : nullptr, stage + 1u, SORT_NO_PLAN);
     }
     return launches;
 }

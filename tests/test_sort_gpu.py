@@ -89,8 +89,8 @@ def test_a_single_far_mover_forces_the_per_stage_plan(fs, orc):
 
 
 @pytest.mark.parametrize("kind", ["moved", "random", "far_mover"])
-def test_compact_late_launches_at_4m(fs, orc, kind):
-    # above 2M elements the gated late stages run in their compact forms (k_bitonic_tail_walk, k_bitonic_strided_batch)
+def test_plans_at_4m(fs, orc, kind):
+    # 1024 tiles, 22 stages: every kind of launch of both plans has work to do or to skip
     n = (1 << 22) + 12_345
     rng = np.random.default_rng(99)
     if kind == "moved":
