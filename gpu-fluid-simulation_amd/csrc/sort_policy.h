@@ -8,8 +8,9 @@
 // arrangement whatever the plan, so a stale or wrong guess costs time, never a result.
 //   - a failed certificate: two stages up, and the per-stage launches stand by again until reports pass;
 //   - passed, but only with the full window (fit class 0: less than 2x room): one stage up;
-//   - passed inside a quarter of the window eight reports in a row: one stage down;
-//   - the single stand-by launch replaces the per-stage ones once two reports in a row passed at the current stage.
+//   - passed inside a quarter of the window four reports in a row: one stage down;
+//   - the single stand-by launch replaces the per-stage ones once two reports in a row passed (a failure or an
+//     upload resets that).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,7 +28,7 @@ struct SortPolicy {
     uint32_t skip_seq = 1;          // the report of the first step after create / an upload says nothing about the flow
     int stage = 0;                  // 0: not chosen yet
     int roomy = 0;                  // consecutive reports with the moves inside a quarter of the window
-    int trusted = 0;                // consecutive passing reports at the current stage
+    int trusted = 0;                // consecutive passing reports
     bool enabled = false;
     bool force_single = false;      // FS_SORT_TRUST=1 (tests): the single stand-by launch from the first step on
     int fixed_stage = -1;           // FS_SORT_FUSE_STAGE at create: a fixed stage (0: per-stage launches only), no policy
@@ -89,12 +90,13 @@ struct SortPolicy {
                 if (st + 2 > stage) stage = st + 2;
                 trusted = 0; roomy = 0;
             } else if (cls == 0) {
-                if (st + 1 > stage) { stage = st + 1; trusted = 0; }
-                roomy = 0;
+                if (st + 1 > stage) stage = st + 1;     // a wider window is safer: the trust stays
+                trusted += 1; roomy = 0;
             } else {
-                if (st == stage) trusted += 1;
+                trusted += 1;
                 roomy = (cls >= 2 && st == stage) ? roomy + 1 : 0;
-                if (roomy >= 8 && stage > 13) { stage -= 1; roomy = 0; trusted = 0; }
+                // inside a quarter of the window: one stage down still leaves 2x room, the trust stays
+                if (roomy >= 4 && stage > 13) { stage -= 1; roomy = 0; }
             }
             if (stage > (int)S - 1) stage = (int)S - 1;
         }
