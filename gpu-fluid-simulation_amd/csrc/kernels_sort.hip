@@ -525,12 +525,12 @@ static int sort_skip_stage() {
 // Fit class: the largest j <= 3 for which (C2), (C3) still hold with windows of H / 2^j — how much room the moves of
 // this step left; the host's choice of the next steps' stage reads it (engine.hip), never the result.
 // feedback (optional, host-visible): [1] stage, [2] verdict, [3] fit class, [4] time-outs, then [0] = seq.
-__global__ __launch_bounds__(1024) void k_late_cert(const u64* __restrict__ pairs, uint32_t n, uint32_t p2, uint32_t s0,
+__global__ __launch_bounds__(256) void k_late_cert(const u64* __restrict__ pairs, uint32_t n, uint32_t p2, uint32_t s0,
                                                     uint32_t* __restrict__ plan, uint32_t* __restrict__ feedback,
                                                     uint32_t seq) {
     const uint32_t H = 1u << (s0 - 1u), nb = p2 >> s0;
     int ok = 1, ok1 = 1, ok2 = 1, ok3 = 1;
-    for (uint32_t b = 1u + threadIdx.x; b < nb; b += 1024u) {
+    for (uint32_t b = 1u + threadIdx.x; b < nb; b += 256u) {
         const uint32_t m = b << s0;
 #define FS_KEY(p) ((p) < n ? (uint32_t)(pairs[(p)] >> 32) : 0xFFFFFFFFu)
         const uint32_t left_max = FS_KEY(m - 1u), right_min = FS_KEY(m);
@@ -705,7 +705,7 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
         if (s0 && stage == s0) {
             // verdict, then the shifted merge (runs when the verdict is 1); stages s0 .. S-1 below run when it is 0
             const uint32_t H = 1u << (s0 - 1u);
-            hipLaunchKernelGGL(k_late_cert, dim3(1), dim3(1024), 0, st, pairs, n, p2, s0, gate,
+            hipLaunchKernelGGL(k_late_cert, dim3(1), dim3(256), 0, st, pairs, n, p2, s0, gate,
                                plan ? plan->feedback : (uint32_t*)nullptr, plan ? plan->seq : 0u);
             ++launches;
             if (n > H)

@@ -1049,7 +1049,7 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
         else { if (aos_out) FS_LAUNCH_FORCE(K, 0, true, G, S, W); else FS_LAUNCH_FORCE(K, 0, false, G, S, W); }      \
     } while (0)
 #ifndef FS_GENERAL_GRID
-#define FS_GENERAL_GRID 1024u
+#define FS_GENERAL_GRID 4096u   // 16M, steps 150-250: force 1.175 (1024) -> 1.126 (2048) -> 1.117 ms (4096); steps 10-110 unchanged
 #endif
     const uint32_t gg = nb < FS_GENERAL_GRID ? nb : FS_GENERAL_GRID;
     if (side) {   // fork: the pre-registered waves on the second stream, beside the lean kernel
