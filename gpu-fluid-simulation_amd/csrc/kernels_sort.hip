@@ -155,6 +155,29 @@ __device__ __forceinline__ void lt_store_l3(u64* __restrict__ pairs, const u64 (
     }
 }
 
+// The tile leaves the network in the L3 layout (16 contiguous elements per thread): stored from there, a wave's
+// store instruction touches 64 different 128-byte lines, 16 bytes each.  One more trip through LDS puts it into the
+// L1 layout, whose stores are 512 contiguous bytes per wave instruction.  (A wave's L3 positions are its own: no
+// barrier before the write; the L1 reads cross waves: one barrier after it.)
+#ifndef FS_SORT_STORE_L3
+__device__ __forceinline__ void lt_store(u64* __restrict__ pairs, u64* s, u64 (&x)[LT_E], uint32_t base, uint32_t t,
+                                         uint32_t n, bool in_lds = false) {
+    if (!in_lds) lt_write<0, 3, false>(s, x, t);
+    __syncthreads();
+    lt_read<8, 3, false>(s, x, t);
+#pragma unroll
+    for (int r = 0; r < LT_E; ++r) {
+        const uint32_t j = ((uint32_t)r << 8) | t;
+        if (base + j < n) pairs[base + j] = x[r];
+    }
+}
+#else
+__device__ __forceinline__ void lt_store(u64* __restrict__ pairs, u64* s, u64 (&x)[LT_E], uint32_t base, uint32_t t,
+                                         uint32_t n, bool in_lds = false) {
+    lt_store_l3(pairs, x, base, t, n);
+}
+#endif
+
 // Late-stage plans (see k_late_cert): `*gate` holds the certificate's verdict; a launch runs when it lies in [lo, hi].
 __device__ __forceinline__ bool gate_closed(const uint32_t* gate, uint32_t lo, uint32_t hi) {
     if (!gate) return false;
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
             for (int r = 0; r + 1 < LT_E; ++r) ok &= (uint32_t)(x[r] >> 32) <= (uint32_t)(x[r + 1] >> 32);
             if (t + 1u < SORT_THREADS) ok &= (uint32_t)(x[LT_E - 1] >> 32) <= (uint32_t)(s[lt_pad((t + 1u) << 4)] >> 32);
             if (__syncthreads_and(ok)) {
-                lt_store_l3(pairs, x, base, t, n);
+                lt_store(pairs, s, x, base, t, n, true);   // the tile is still in LDS at its natural positions
                 if (t == 0) dirty[blockIdx.x] = 0;
                 return;
             }
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
     } else {
         lt_tail(pairs, n, base, s, x, t);
     }
-    lt_store_l3(pairs, x, base, t, n);
+    lt_store(pairs, s, x, base, t, n);
     if (t == 0) dirty[blockIdx.x] = 0;                 // sorted again
 }
 
@@ -298,13 +321,13 @@ __global__ __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
     for (int r = 0; r < LT_E; ++r) lt_cx(xa[r], xb[r]);            // A[j] vs B[4095 - j]: the stage's mirror step
     lt_tail_regs(s, xa, t, t);
-    lt_store_l3(pairs, xa, base_a, t, n);
+    lt_store(pairs, s, xa, base_a, t, n);
     u64 xn[LT_E];
 #pragma unroll
     for (int r = 0; r < LT_E; ++r) xn[r] = xb[LT_E - 1 - r];        // natural order of thread 255 - t
     __syncthreads();                                   // A's last LDS reads are done
     lt_tail_regs(s, xn, SORT_THREADS - 1u - t, t);
-    lt_store_l3(pairs, xn, base_b, t, n);
+    lt_store(pairs, s, xn, base_b, t, n);
 }
 
 // M consecutive global steps of one stage in ONE pass, register-blocked: a thread owns the
@@ -620,7 +643,7 @@ __global__ __launch_bounds__(256) void k_late_fallback(u64* pairs, uint32_t n, u
             const uint32_t base = tile * SORT_T;
             u64 x[LT_E];
             lt_tail(pairs, n, base, s, x, t);
-            lt_store_l3(pairs, x, base, t, n);
+            lt_store(pairs, s, x, base, t, n);
             if (t == 0) dirty[tile] = 0;
             __syncthreads();                           // the LDS stage is reused
         }
