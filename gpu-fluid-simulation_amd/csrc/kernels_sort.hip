@@ -27,41 +27,53 @@ namespace fsd {
 #define SORT_THREADS 256
 
 // ------------------------------------------------------------------ tile-local kernels
-// Register-blocked: 256 threads x 16 elements.  The 12 index bits of a tile are split in
-// three groups of four; a thread holds the 16 elements that differ in ONE group, so four
-// consecutive steps run in VGPRs, and the tile is re-distributed through LDS between
-// groups (instead of one LDS round trip per step):
-//   L1: in-thread bits 11..8   idx = (r << 8) | t          (also the coalesced global layout)
-//   L2: in-thread bits  7..4   idx = (t>>4 << 8) | (r << 4) | (t & 15)
-//   L3: in-thread bits  3..0   idx = (t << 4) | r          (16 contiguous elements)
-// LDS addresses are padded by one element per 16 (lt_pad), which makes the 8-byte
-// accesses of all three layouts bank-conflict free (64 x 4-B banks, MI355X guide §LDS).
+// Register-blocked: 2^(12-GB) threads x E = 2^GB elements.  The 12 index bits of a tile are split in groups of GB;
+// a thread holds the E elements that differ in ONE group, so GB consecutive steps run in VGPRs, and the tile is
+// re-distributed through LDS between groups (instead of one LDS round trip per step).  Layout of group g (in-thread
+// bits [g GB, (g+1) GB), B = g GB):   idx = (t >> B) << (B + GB) | r << B | t & (2^B - 1)
+// — the top group is also the coalesced global layout (idx = r << (12-GB) | t), group 0 holds E contiguous elements.
+//   GB = 4: 256 threads x 16 elements, three groups — the default;
+//   GB = 3: 512 threads x  8 elements, four groups: twice the waves per tile (the tile's LDS footprint bounds the
+//           occupancy: four tiles per CU) for a third more LDS round trips.  Measured at 16M: first kernel 179 -> 190 us,
+//           tails equal, stage 12 42 -> 38 us, sort 0.435 -> 0.445 ms: not the default (-DFS_SORT_GB=3 builds it).
+// LDS addresses are padded (lt_pad) so that the 8-byte accesses of all layouts are bank-conflict free, or 2-way at
+// worst (64 x 4-B banks; GB = 3: chosen by enumeration over the layouts and their mirrored reads).
 // The mirror step of stage s is done as in k_bitonic_strided: rows with bit s set are read
 // from idx ^ (2^s - 1), after which it is a plain distance-2^s step and the remaining steps
 // of that round compare in reversed order on those rows.
-#define LT_E 16
+#ifndef FS_SORT_GB
+#define FS_SORT_GB 4
+#endif
+template <int GB> struct LT {
+    static constexpr int E = 1 << GB;                     // elements per thread
+    static constexpr int THREADS = (int)SORT_T >> GB;
+    static constexpr int TOPB = SORT_LOG_T - GB;          // bit position of the top group
+    static constexpr int NG = SORT_LOG_T / GB;            // groups
+    static constexpr int LDS = GB == 4 ? (int)SORT_T + ((int)SORT_T >> 4) : 4384;
+};
 
-__device__ __forceinline__ uint32_t lt_pad(uint32_t idx) { return idx + (idx >> 4); }
-#define LT_LDS_ELEMS (SORT_T + (SORT_T >> 4))
+template <int GB>
+__device__ __forceinline__ uint32_t lt_pad(uint32_t idx) {
+    if (GB == 4) return idx + (idx >> 4);
+    return idx + ((idx >> 5) << 1) + (idx >> 7);          // max 4380
+}
 
-template <int B>
+template <int GB, int B>
 __device__ __forceinline__ uint32_t lt_idx(uint32_t r, uint32_t t) {
-    if (B == 8) return (r << 8) | t;
-    if (B == 4) return ((t >> 4) << 8) | (r << 4) | (t & 15u);
-    return (t << 4) | r;
+    return ((t >> B) << (B + GB)) | (r << B) | (t & ((1u << B) - 1u));
 }
 
 __device__ __forceinline__ void lt_cx(u64& lo, u64& hi) {     // lo = physically lower element
     if ((uint32_t)(lo >> 32) > (uint32_t)(hi >> 32)) { const u64 t = lo; lo = hi; hi = t; }
 }
 
-// Steps on in-thread bits TOP..0 of group B.  FLIP: the step on bit TOP is a stage's mirror step.
-template <int TOP, bool FLIP>
-__device__ __forceinline__ void lt_round(u64 (&x)[LT_E]) {
+// Steps on in-thread bits TOP..0 of a group.  FLIP: the step on bit TOP is a stage's mirror step.
+template <int GB, int TOP, bool FLIP>
+__device__ __forceinline__ void lt_round(u64 (&x)[1 << GB]) {
 #pragma unroll
     for (int b = TOP; b >= 0; --b) {
 #pragma unroll
-        for (int r = 0; r < LT_E; ++r) {
+        for (int r = 0; r < (1 << GB); ++r) {
             if (r & (1 << b)) continue;
             const int r1 = r | (1 << b);
             if (FLIP && b < TOP && ((r >> TOP) & 1)) lt_cx(x[r1], x[r]);   // reversed rows (see header)
@@ -70,113 +82,91 @@ __device__ __forceinline__ void lt_round(u64 (&x)[LT_E]) {
     }
 }
 
-template <int B, int TOP, bool FLIP>
-__device__ __forceinline__ void lt_read(const u64* s, u64 (&x)[LT_E], uint32_t t) {
+template <int GB, int B, int TOP, bool FLIP>
+__device__ __forceinline__ void lt_read(const u64* s, u64 (&x)[1 << GB], uint32_t t) {
 #pragma unroll
-    for (int r = 0; r < LT_E; ++r) {
-        uint32_t idx = lt_idx<B>((uint32_t)r, t);
+    for (int r = 0; r < (1 << GB); ++r) {
+        uint32_t idx = lt_idx<GB, B>((uint32_t)r, t);
         if (FLIP && ((r >> TOP) & 1)) idx ^= (1u << (B + TOP)) - 1u;
-        x[r] = s[lt_pad(idx)];
+        x[r] = s[lt_pad<GB>(idx)];
     }
 }
 
-template <int B, int TOP, bool FLIP>
-__device__ __forceinline__ void lt_write(u64* s, const u64 (&x)[LT_E], uint32_t t) {
+template <int GB, int B, int TOP, bool FLIP>
+__device__ __forceinline__ void lt_write(u64* s, const u64 (&x)[1 << GB], uint32_t t) {
 #pragma unroll
-    for (int r = 0; r < LT_E; ++r) {
-        uint32_t idx = lt_idx<B>((uint32_t)r, t);
+    for (int r = 0; r < (1 << GB); ++r) {
+        uint32_t idx = lt_idx<GB, B>((uint32_t)r, t);
         if (FLIP && ((r >> TOP) & 1)) idx ^= (1u << (B + TOP)) - 1u;
-        s[lt_pad(idx)] = x[r];
+        s[lt_pad<GB>(idx)] = x[r];
     }
 }
 
-// L2 <-> L3 re-distribution only exchanges data between the 16 consecutive threads that share
-// t >> 4 (L2 thread (hi4, lo4) owns idx = hi4<<8 | r<<4 | lo4, which in L3 belongs to thread
-// hi4<<4 | r): always inside one wave.  A wave's LDS instructions execute in program order, so
-// no workgroup barrier is needed there — only a compiler-level fence.  L1 <-> L2/L3 crosses waves.
+// A re-distribution that involves group G exchanges data between the 2^(G GB) threads that share t >> (G GB).  Up to 64
+// of them that is one wave: a wave's LDS instructions execute in program order, so no workgroup barrier is needed
+// there — only a compiler-level fence.
 __device__ __forceinline__ void lt_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+template <int GB, int G>
+__device__ __forceinline__ void lt_sync() {
+    if (G * GB > 6) __syncthreads();
+    else lt_wave_sync();
+}
 
-// Stage S (0..3) entirely on in-thread bits of L3.
-template <int S>
-__device__ __forceinline__ void lt_stage_regs(u64 (&x)[LT_E]) {
-#pragma unroll
-    for (int r = 0; r < LT_E; ++r) {
-        if (r & (1 << S)) continue;
-        lt_cx(x[r], x[r ^ ((2 << S) - 1)]);          // mirror inside the 2^(S+1) block
+// From group G (just written to LDS in its layout) down to group 0: the remaining plain steps of a stage or tail.
+template <int GB, int G>
+__device__ __forceinline__ void lt_descend(u64* s, u64 (&x)[1 << GB], uint32_t t) {
+    if constexpr (G > 0) {
+        lt_sync<GB, G>();
+        lt_read<GB, (G - 1) * GB, GB - 1, false>(s, x, t);
+        lt_round<GB, GB - 1, false>(x);
+        if constexpr (G - 1 > 0) {
+            lt_write<GB, (G - 1) * GB, GB - 1, false>(s, x, t);
+            lt_descend<GB, G - 1>(s, x, t);
+        }
     }
-    if (S > 0) lt_round<(S > 0 ? S - 1 : 0), false>(x);
 }
 
-// Stage S in 4..7: mirror + steps down to bit 4 in L2, then bits 3..0 in L3.
-template <int S>
-__device__ __forceinline__ void lt_stage_mid(u64* s, u64 (&x)[LT_E], uint32_t t) {
-    lt_write<0, 3, false>(s, x, t);
-    lt_wave_sync();                       // L3 -> L2 (mirrored reads stay inside the 2^(S+1) block, S <= 7: same 16 threads)
-    lt_read<4, S - 4, true>(s, x, t);
-    lt_round<S - 4, true>(x);
-    lt_write<4, S - 4, true>(s, x, t);
-    lt_wave_sync();                       // L2 -> L3
-    lt_read<0, 3, false>(s, x, t);
-    lt_round<3, false>(x);
-}
-
-// Stage S in 8..11: mirror + steps down to bit 8 in L1, bits 7..4 in L2, bits 3..0 in L3.
-template <int S>
-__device__ __forceinline__ void lt_stage_high(u64* s, u64 (&x)[LT_E], uint32_t t) {
-    lt_write<0, 3, false>(s, x, t);
-    __syncthreads();
-    lt_read<8, S - 8, true>(s, x, t);
-    lt_round<S - 8, true>(x);
-    lt_write<8, S - 8, true>(s, x, t);
-    __syncthreads();
-    lt_read<4, 3, false>(s, x, t);
-    lt_round<3, false>(x);
-    lt_write<4, 3, false>(s, x, t);
-    lt_wave_sync();                       // L2 -> L3
-    lt_read<0, 3, false>(s, x, t);
-    lt_round<3, false>(x);
-}
-
-__device__ __forceinline__ void lt_store_l3(u64* __restrict__ pairs, const u64 (&x)[LT_E], uint32_t base,
-                                            uint32_t t, uint32_t n) {
-    const uint32_t g0 = base + (t << 4);
-    if (g0 + LT_E <= n) {
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(pairs + g0);      // 128-B aligned
+// Stage S (0..11) of the network inside a tile; on entry and exit the tile is in the group-0 layout, in registers.
+template <int GB, int S>
+__device__ __forceinline__ void lt_stage(u64* s, u64 (&x)[1 << GB], uint32_t t) {
+    constexpr int G = S / GB, TOP = S % GB;
+    if constexpr (G == 0) {
 #pragma unroll
-        for (int r = 0; r < LT_E; r += 2) dst[r >> 1] = make_ulonglong2(x[r], x[r + 1]);
+        for (int r = 0; r < (1 << GB); ++r) {
+            if (r & (1 << S)) continue;
+            lt_cx(x[r], x[r ^ ((2 << S) - 1)]);          // mirror inside the 2^(S+1) block
+        }
+        if constexpr (S > 0) lt_round<GB, (S > 0 ? S - 1 : 0), false>(x);
     } else {
-#pragma unroll
-        for (int r = 0; r < LT_E; ++r)
-            if (g0 + r < n) pairs[g0 + r] = x[r];
+        lt_write<GB, 0, GB - 1, false>(s, x, t);
+        lt_sync<GB, G>();                 // group 0 -> group G (mirrored reads stay inside the 2^(S+1) block: same threads)
+        lt_read<GB, G * GB, TOP, true>(s, x, t);
+        lt_round<GB, TOP, true>(x);
+        lt_write<GB, G * GB, TOP, true>(s, x, t);
+        lt_descend<GB, G>(s, x, t);
     }
 }
 
-// The tile leaves the network in the L3 layout (16 contiguous elements per thread): stored from there, a wave's
-// store instruction touches 64 different 128-byte lines, 16 bytes each.  One more trip through LDS puts it into the
-// L1 layout, whose stores are 512 contiguous bytes per wave instruction.  (A wave's L3 positions are its own: no
-// barrier before the write; the L1 reads cross waves: one barrier after it.)
-#ifndef FS_SORT_STORE_L3
-__device__ __forceinline__ void lt_store(u64* __restrict__ pairs, u64* s, u64 (&x)[LT_E], uint32_t base, uint32_t t,
+// The tile leaves the network in the group-0 layout (E contiguous elements per thread): stored from there, a wave's
+// store instruction touches 64 different lines, 16 bytes each.  One more trip through LDS puts it into the top
+// layout, whose stores are 512 contiguous bytes per wave instruction.  (A thread's group-0 positions are its own: no
+// barrier before the write; the top-layout reads cross waves: one barrier after it.)
+template <int GB>
+__device__ __forceinline__ void lt_store(u64* __restrict__ pairs, u64* s, u64 (&x)[1 << GB], uint32_t base, uint32_t t,
                                          uint32_t n, bool in_lds = false) {
-    if (!in_lds) lt_write<0, 3, false>(s, x, t);
+    if (!in_lds) lt_write<GB, 0, GB - 1, false>(s, x, t);
     __syncthreads();
-    lt_read<8, 3, false>(s, x, t);
+    lt_read<GB, LT<GB>::TOPB, GB - 1, false>(s, x, t);
 #pragma unroll
-    for (int r = 0; r < LT_E; ++r) {
-        const uint32_t j = ((uint32_t)r << 8) | t;
+    for (int r = 0; r < (1 << GB); ++r) {
+        const uint32_t j = ((uint32_t)r << LT<GB>::TOPB) | t;
         if (base + j < n) pairs[base + j] = x[r];
     }
 }
-#else
-__device__ __forceinline__ void lt_store(u64* __restrict__ pairs, u64* s, u64 (&x)[LT_E], uint32_t base, uint32_t t,
-                                         uint32_t n, bool in_lds = false) {
-    lt_store_l3(pairs, x, base, t, n);
-}
-#endif
 
 // Late-stage plans (see k_late_cert): `*gate` holds the certificate's verdict; a launch runs when it lies in [lo, hi].
 __device__ __forceinline__ bool gate_closed(const uint32_t* gate, uint32_t lo, uint32_t hi) {
@@ -185,23 +175,25 @@ __device__ __forceinline__ bool gate_closed(const uint32_t* gate, uint32_t lo, u
     return v < lo || v > hi;
 }
 
-// tail of a stage >= 12: plain steps on bits 11..0 of one tile; the L1 view IS the coalesced global layout
-__device__ __forceinline__ void lt_tail(const u64* __restrict__ pairs, uint32_t n, uint32_t base, u64* s, u64 (&x)[LT_E],
+// The twelve plain steps of a tail on a tile already in registers (top layout as held by thread `t1`: the caller may
+// hold the tile mirrored, see k_bitonic_stage12), ending in the group-0 layout of the real thread.
+template <int GB>
+__device__ __forceinline__ void lt_tail_regs(u64* s, u64 (&x)[1 << GB], uint32_t t1, uint32_t t) {
+    lt_round<GB, GB - 1, false>(x);
+    lt_write<GB, LT<GB>::TOPB, GB - 1, false>(s, x, t1);
+    lt_descend<GB, LT<GB>::NG - 1>(s, x, t);
+}
+
+// tail of a stage >= 12: plain steps on bits 11..0 of one tile; the top layout IS the coalesced global layout
+template <int GB>
+__device__ __forceinline__ void lt_tail(const u64* __restrict__ pairs, uint32_t n, uint32_t base, u64* s, u64 (&x)[1 << GB],
                                         uint32_t t) {
 #pragma unroll
-    for (int r = 0; r < LT_E; ++r) {
-        const uint32_t j = ((uint32_t)r << 8) | t;
+    for (int r = 0; r < (1 << GB); ++r) {
+        const uint32_t j = ((uint32_t)r << LT<GB>::TOPB) | t;
         x[r] = (base + j < n) ? pairs[base + j] : ~0ull;
     }
-    lt_round<3, false>(x);
-    lt_write<8, 3, false>(s, x, t);
-    __syncthreads();
-    lt_read<4, 3, false>(s, x, t);
-    lt_round<3, false>(x);
-    lt_write<4, 3, false>(s, x, t);
-    lt_wave_sync();                   // L2 -> L3
-    lt_read<0, 3, false>(s, x, t);
-    lt_round<3, false>(x);
+    lt_tail_regs<GB>(s, x, t, t);
 }
 
 // `dirty[tile]` != 0 when a strided pass of the current stage swapped an element of the tile.
@@ -211,28 +203,29 @@ __device__ __forceinline__ void lt_tail(const u64* __restrict__ pairs, uint32_t 
 // KEYGEN (2D engine): the init pass also IS predict_next_position + create_spatial_lookup
 // (compute.wgsl:8-42): it reads pos/vel and builds the (key, index) pairs on the fly instead of
 // reading them — one launch and one write+read of the pair array less per step.
-template <bool INIT, bool KEYGEN>
-__global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict__ pairs, uint32_t n,
-                                                                uint32_t num_stages, uint32_t* __restrict__ dirty,
-                                                                StepParams P, const float2* __restrict__ pos,
-                                                                const float2* __restrict__ vel,
-                                                                uint32_t* __restrict__ gap_counter,
-                                                                const uint32_t* __restrict__ gate = nullptr,
-                                                                uint32_t gate_lo = 0, uint32_t gate_hi = 0) {
-    __shared__ u64 s[LT_LDS_ELEMS];
+template <bool INIT, bool KEYGEN, int GB>
+__global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_local(u64* __restrict__ pairs, uint32_t n,
+                                                                   uint32_t num_stages, uint32_t* __restrict__ dirty,
+                                                                   StepParams P, const float2* __restrict__ pos,
+                                                                   const float2* __restrict__ vel,
+                                                                   uint32_t* __restrict__ gap_counter,
+                                                                   const uint32_t* __restrict__ gate = nullptr,
+                                                                   uint32_t gate_lo = 0, uint32_t gate_hi = 0) {
+    constexpr int E = LT<GB>::E;
+    __shared__ u64 s[LT<GB>::LDS];
     const uint32_t base = blockIdx.x * SORT_T;
     const uint32_t t = threadIdx.x;
     if (!INIT) {
         if (gate_closed(gate, gate_lo, gate_hi)) return;   // uniform: this launch belongs to the other late-stage plan
         if (dirty[blockIdx.x] == 0) return;            // uniform: whole tile provably unchanged
     }
-    u64 x[LT_E];
+    u64 x[E];
     if (INIT) {
         if (KEYGEN && blockIdx.x == 0 && t == 0) *gap_counter = 0;      // consumed by k_reorder later in the stream
-        // coalesced load, straight into LDS, then the L3 view
+        // coalesced load, straight into LDS, then the group-0 view
 #pragma unroll
-        for (int r = 0; r < LT_E; ++r) {
-            const uint32_t j = ((uint32_t)r << 8) | t;
+        for (int r = 0; r < E; ++r) {
+            const uint32_t j = ((uint32_t)r << LT<GB>::TOPB) | t;
             u64 v = ~0ull;
             if (base + j < n) {
                 if (KEYGEN) {
@@ -242,10 +235,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
                     v = pairs[base + j];
                 }
             }
-            s[lt_pad(j)] = v;
+            s[lt_pad<GB>(j)] = v;
         }
         __syncthreads();
-        lt_read<0, 3, false>(s, x, t);
+        lt_read<GB, 0, GB - 1, false>(s, x, t);
         {   // A tile whose keys are already in order passes through the network unchanged: every compare-exchange of
             // an ascending network tests key[lower index] > key[higher index], which never holds (strict compare, so
             // equal keys stay put as well).  While the fluid still moves as a lattice whole steps change no key at
@@ -253,56 +246,44 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bitonic_local(u64* __restrict_
             // 16M dam break: 190 -> ~55 us).
             int ok = 1;
 #pragma unroll
-            for (int r = 0; r + 1 < LT_E; ++r) ok &= (uint32_t)(x[r] >> 32) <= (uint32_t)(x[r + 1] >> 32);
-            if (t + 1u < SORT_THREADS) ok &= (uint32_t)(x[LT_E - 1] >> 32) <= (uint32_t)(s[lt_pad((t + 1u) << 4)] >> 32);
+            for (int r = 0; r + 1 < E; ++r) ok &= (uint32_t)(x[r] >> 32) <= (uint32_t)(x[r + 1] >> 32);
+            if (t + 1u < (uint32_t)LT<GB>::THREADS) ok &= (uint32_t)(x[E - 1] >> 32) <= (uint32_t)(s[lt_pad<GB>((t + 1u) << GB)] >> 32);
             if (__syncthreads_and(ok)) {
-                lt_store(pairs, s, x, base, t, n, true);   // the tile is still in LDS at its natural positions
+                lt_store<GB>(pairs, s, x, base, t, n, true);   // the tile is still in LDS at its natural positions
                 if (t == 0) dirty[blockIdx.x] = 0;
                 return;
             }
         }
-        lt_stage_regs<0>(x);
-        if (num_stages > 1) lt_stage_regs<1>(x);
-        if (num_stages > 2) lt_stage_regs<2>(x);
-        if (num_stages > 3) lt_stage_regs<3>(x);
-        if (num_stages > 4) lt_stage_mid<4>(s, x, t);
-        if (num_stages > 5) lt_stage_mid<5>(s, x, t);
-        if (num_stages > 6) lt_stage_mid<6>(s, x, t);
-        if (num_stages > 7) lt_stage_mid<7>(s, x, t);
-        if (num_stages > 8) lt_stage_high<8>(s, x, t);
-        if (num_stages > 9) lt_stage_high<9>(s, x, t);
-        if (num_stages > 10) lt_stage_high<10>(s, x, t);
-        if (num_stages > 11) lt_stage_high<11>(s, x, t);
+        lt_stage<GB, 0>(s, x, t);
+        if (num_stages > 1) lt_stage<GB, 1>(s, x, t);
+        if (num_stages > 2) lt_stage<GB, 2>(s, x, t);
+        if (num_stages > 3) lt_stage<GB, 3>(s, x, t);
+        if (num_stages > 4) lt_stage<GB, 4>(s, x, t);
+        if (num_stages > 5) lt_stage<GB, 5>(s, x, t);
+        if (num_stages > 6) lt_stage<GB, 6>(s, x, t);
+        if (num_stages > 7) lt_stage<GB, 7>(s, x, t);
+        if (num_stages > 8) lt_stage<GB, 8>(s, x, t);
+        if (num_stages > 9) lt_stage<GB, 9>(s, x, t);
+        if (num_stages > 10) lt_stage<GB, 10>(s, x, t);
+        if (num_stages > 11) lt_stage<GB, 11>(s, x, t);
     } else {
-        lt_tail(pairs, n, base, s, x, t);
+        lt_tail<GB>(pairs, n, base, s, x, t);
     }
-    lt_store(pairs, s, x, base, t, n);
+    lt_store<GB>(pairs, s, x, base, t, n);
     if (t == 0) dirty[blockIdx.x] = 0;                 // sorted again
 }
 
-// The twelve plain steps of a tail on a tile already in registers (L1 layout as held by thread `t1`: the caller may hold
-// the tile mirrored, see k_bitonic_stage12), ending in the L3 layout of the real thread.
-__device__ __forceinline__ void lt_tail_regs(u64* s, u64 (&x)[LT_E], uint32_t t1, uint32_t t) {
-    lt_round<3, false>(x);
-    lt_write<8, 3, false>(s, x, t1);
-    __syncthreads();
-    lt_read<4, 3, false>(s, x, t);
-    lt_round<3, false>(x);
-    lt_write<4, 3, false>(s, x, t);
-    lt_wave_sync();                   // L2 -> L3
-    lt_read<0, 3, false>(s, x, t);
-    lt_round<3, false>(x);
-}
-
 // Stage 12 in ONE kernel: its only global step is the mirror step between the two tiles of an 8192-block, so a
-// workgroup takes both tiles: A in the L1 layout, B read back to front (thread t holds B[4095 - (r << 8 | t)], still
-// a coalesced load) — the mirror partners then sit in the same register slot of the same thread.  After the
-// compare-exchanges A's tail runs from the registers; B's registers, renamed r -> 15 - r, ARE the L1 layout of thread
-// 255 - t, so its tail only writes its first LDS round with that thread id.  Saves the strided pass (one read + write of
-// the pair array) and a launch.  Certificate: last(A) <= first(B) (both tiles are sorted on entry) => no compare of the
-// stage can swap; otherwise the pair (last(A), first(B)) itself swaps and both tails are needed.
-__global__ __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bitonic_stage12(u64* __restrict__ pairs, uint32_t n) {
-    __shared__ u64 s[LT_LDS_ELEMS];
+// workgroup takes both tiles: A in the top layout, B read back to front (thread t holds B[4095 - (r << TOPB | t)],
+// still a coalesced load) — the mirror partners then sit in the same register slot of the same thread.  After the
+// compare-exchanges A's tail runs from the registers; B's registers, renamed r -> E-1 - r, ARE the top layout of thread
+// THREADS-1 - t, so its tail only writes its first LDS round with that thread id.  Saves the strided pass (one read +
+// write of the pair array) and a launch.  Certificate: last(A) <= first(B) (both tiles are sorted on entry) => no
+// compare of the stage can swap; otherwise the pair (last(A), first(B)) itself swaps and both tails are needed.
+template <int GB>
+__global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_stage12(u64* __restrict__ pairs, uint32_t n) {
+    constexpr int E = LT<GB>::E;
+    __shared__ u64 s[LT<GB>::LDS];
     const uint32_t t = threadIdx.x;
     const uint32_t base_a = blockIdx.x * (2u * SORT_T), base_b = base_a + SORT_T;
     if (base_b >= n) return;                           // B holds sentinels only: nothing can swap
@@ -310,24 +291,24 @@ __global__ __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         const uint32_t last_a = (uint32_t)(pairs[base_b - 1u] >> 32), first_b = (uint32_t)(pairs[base_b] >> 32);
         if (last_a <= first_b) return;                 // uniform
     }
-    u64 xa[LT_E], xb[LT_E];
+    u64 xa[E], xb[E];
 #pragma unroll
-    for (int r = 0; r < LT_E; ++r) {
-        const uint32_t j = ((uint32_t)r << 8) | t;
+    for (int r = 0; r < E; ++r) {
+        const uint32_t j = ((uint32_t)r << LT<GB>::TOPB) | t;
         xa[r] = pairs[base_a + j];                     // base_b < n: A is complete
         const uint32_t pb = base_b + (SORT_T - 1u - j);
         xb[r] = pb < n ? pairs[pb] : ~0ull;
     }
 #pragma unroll
-    for (int r = 0; r < LT_E; ++r) lt_cx(xa[r], xb[r]);            // A[j] vs B[4095 - j]: the stage's mirror step
-    lt_tail_regs(s, xa, t, t);
-    lt_store(pairs, s, xa, base_a, t, n);
-    u64 xn[LT_E];
+    for (int r = 0; r < E; ++r) lt_cx(xa[r], xb[r]);               // A[j] vs B[4095 - j]: the stage's mirror step
+    lt_tail_regs<GB>(s, xa, t, t);
+    lt_store<GB>(pairs, s, xa, base_a, t, n);
+    u64 xn[E];
 #pragma unroll
-    for (int r = 0; r < LT_E; ++r) xn[r] = xb[LT_E - 1 - r];        // natural order of thread 255 - t
+    for (int r = 0; r < E; ++r) xn[r] = xb[E - 1 - r];             // natural order of thread THREADS-1 - t
     __syncthreads();                                   // A's last LDS reads are done
-    lt_tail_regs(s, xn, SORT_THREADS - 1u - t, t);
-    lt_store(pairs, s, xn, base_b, t, n);
+    lt_tail_regs<GB>(s, xn, (uint32_t)LT<GB>::THREADS - 1u - t, t);
+    lt_store<GB>(pairs, s, xn, base_b, t, n);
 }
 
 // M consecutive global steps of one stage in ONE pass, register-blocked: a thread owns the
@@ -618,7 +599,7 @@ __global__ __launch_bounds__(256) void k_late_fallback(u64* pairs, uint32_t n, u
                                                        uint32_t* dirty, uint32_t* plan) {
     if (plan[0] != SORT_NO_PLAN) return;               // uniform over the grid: the shifted merge did the work
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&plan[6], 1u);   // diagnostics: calls this kernel had to work in
-    __shared__ u64 s[LT_LDS_ELEMS];
+    __shared__ u64 s[LT<4>::LDS];                       // 256 threads: the 16-element form of the tile code
     __shared__ uint32_t s_first[256], s_last[256];
     __shared__ uint32_t s_active;
     const uint32_t tiles = (n + SORT_T - 1) / SORT_T, t = threadIdx.x;
@@ -641,9 +622,9 @@ __global__ __launch_bounds__(256) void k_late_fallback(u64* pairs, uint32_t n, u
         for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
             if (dirty[tile] == 0) continue;            // uniform
             const uint32_t base = tile * SORT_T;
-            u64 x[LT_E];
-            lt_tail(pairs, n, base, s, x, t);
-            lt_store(pairs, s, x, base, t, n);
+            u64 x[LT<4>::E];
+            lt_tail<4>(pairs, n, base, s, x, t);
+            lt_store<4>(pairs, s, x, base, t, n);
             if (t == 0) dirty[tile] = 0;
             __syncthreads();                           // the LDS stage is reused
         }
@@ -692,7 +673,7 @@ static int launch_stage(hipStream_t st, u64* pairs, uint32_t n, uint32_t p2, uin
     }
     StepParams P0;
     memset(&P0, 0, sizeof P0);
-    hipLaunchKernelGGL((k_bitonic_local<false, false>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, 0u, dirty, P0,
+    hipLaunchKernelGGL((k_bitonic_local<false, false, FS_SORT_GB>), dim3(tiles), dim3(LT<FS_SORT_GB>::THREADS), 0, st, pairs, n, 0u, dirty, P0,
                        (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr, gate, glo, ghi);
     return launches + 1;
 }
@@ -710,10 +691,10 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
     StepParams P0;
     memset(&P0, 0, sizeof P0);
     if (keygen)
-        hipLaunchKernelGGL((k_bitonic_local<true, true>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n, init_stages,
+        hipLaunchKernelGGL((k_bitonic_local<true, true, FS_SORT_GB>), dim3(tiles), dim3(LT<FS_SORT_GB>::THREADS), 0, st, pairs, n, init_stages,
                            dirty, *keygen, pos, vel, gap_counter, (const uint32_t*)nullptr, 0u);
     else
-        hipLaunchKernelGGL((k_bitonic_local<true, false>), dim3(tiles), dim3(SORT_THREADS), 0, st, pairs, n,
+        hipLaunchKernelGGL((k_bitonic_local<true, false, FS_SORT_GB>), dim3(tiles), dim3(LT<FS_SORT_GB>::THREADS), 0, st, pairs, n,
                            init_stages, dirty, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr,
                            (const uint32_t*)nullptr, 0u);
     ++launches;                                         // leaves every tile sorted and its flag cleared
@@ -752,7 +733,7 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
         // a stage at or after the verdict's is already done: these launches then return at once (~5 us each)
         const bool gated = s0 && stage >= s0;
         if (stage == SORT_LOG_T && fused12) {          // (never gated: s0 > SORT_LOG_T)
-            hipLaunchKernelGGL(k_bitonic_stage12, dim3((tiles + 1u) / 2u), dim3(SORT_THREADS), 0, st, pairs, n);
+            hipLaunchKernelGGL((k_bitonic_stage12<FS_SORT_GB>), dim3((tiles + 1u) / 2u), dim3(LT<FS_SORT_GB>::THREADS), 0, st, pairs, n);
             ++launches;
             continue;
         }
