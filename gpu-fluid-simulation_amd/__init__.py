@@ -107,6 +107,19 @@ def selftest_sort(keys, fuse_stage=-1, device=0):
     return (pairs >> np.uint64(32)).astype(np.uint32), (pairs & np.uint64(0xFFFFFFFF)).astype(np.uint32), (plan[0], plan[1])
 
 
+def selftest_sort_policy(required, log2_count=24, start_back=8, lag=4):
+    """Replay the sort-plan policy (csrc/sort_policy.h) on the CPU against a per-step `required` stage; returns
+    (stage chosen per step, single stand-by launch in the stream per step).  See fs_selftest_sort_policy."""
+    lib = load_library()
+    req = np.ascontiguousarray(required, dtype=np.uint32)
+    stage = np.zeros(req.shape[0], dtype=np.uint32)
+    single = np.zeros(req.shape[0], dtype=np.uint32)
+    U = C.POINTER(C.c_uint32)
+    _check(lib, lib.fs_selftest_sort_policy(int(log2_count), int(start_back), int(lag), req.ctypes.data_as(U), req.shape[0],
+                                            stage.ctypes.data_as(U), single.ctypes.data_as(U)))
+    return stage, single
+
+
 class FluidSimulation:
     """FluidSimulation (src/simulation.rs:10-37) on one MI355X, driven through the C ABI."""
 

@@ -243,6 +243,8 @@ PROTOTYPES = {
     "fs3_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "fs_selftest_constdiv": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint32)]),
     "fs_sort_plan_read": (C.c_int, [C.c_void_p, C.POINTER(SortPlanInfo)]),
+    "fs_selftest_sort_policy": (C.c_int, [C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.c_size_t,
+                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "fs_selftest_sort": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]),
     "fs_constdiv_status": (C.c_int, [_P]),
     "fs_buffer_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_char_p, C.POINTER(_P)]),

@@ -788,6 +788,29 @@ fs_status fs_selftest_sort(int device, uint64_t* pairs, uint32_t n, int fuse_sta
     return FS_OK;
 }
 
+/* The plan policy replayed against a model of the flow (include/fluidsim.h); host only. */
+fs_status fs_selftest_sort_policy(uint32_t S, int start_back, uint32_t lag, const uint32_t* required, size_t steps,
+                                  uint32_t* stage_out, uint32_t* single_out) {
+    if (!required || !stage_out || !single_out || S < 15 || S > 28) return fail(FS_ERR_INVALID, "bad argument");
+    fsd::SortPolicy p;
+    p.start_back = start_back;
+    std::vector<uint32_t> used(steps);
+    for (size_t i = 0; i < steps; ++i) {
+        if (i >= lag && i - lag < steps) {             // the report of step i - lag arrives before step i is planned
+            const size_t j = i - lag;
+            const int st = (int)used[j];
+            const bool passed = st >= (int)required[j];
+            const int cls = passed ? (st - (int)required[j] > 3 ? 3 : st - (int)required[j]) : 0;
+            p.observe((uint32_t)j + 1u, st, passed, cls, S);
+        }
+        used[i] = (uint32_t)(p.stage ? p.stage : p.first_stage(S));
+        p.seq = (uint32_t)i + 1u;                      // what plan() does: this step's sequence number
+        stage_out[i] = used[i];
+        single_out[i] = p.single_standby() ? 1u : 0u;
+    }
+    return FS_OK;
+}
+
 fs_status fs_sort_plan_read(fs_sim* s, fs_sort_plan_info* out) {
     if (!s || !out) return fail(FS_ERR_INVALID, "null argument");
     FS_HIP(hipSetDevice(s->device));

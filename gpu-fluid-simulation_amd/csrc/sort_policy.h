@@ -70,6 +70,29 @@ struct SortPolicy {
         return r;
     }
 
+    // One report of the certificate: sequence number, the stage it ran at, its verdict, the fit class.
+    void observe(uint32_t s, int st, bool passed, int cls, uint32_t S) {
+        seen = s;
+        if (stage == 0) stage = st;
+        if (s == skip_seq) {
+            // nothing to learn
+        } else if (!passed) {
+            if (st + 2 > stage) stage = st + 2;
+            trusted = 0; roomy = 0;
+        } else if (cls == 0) {
+            if (st + 1 > stage) stage = st + 1;     // a wider window is safer: the trust stays
+            trusted += 1; roomy = 0;
+        } else {
+            trusted += 1;
+            roomy = (cls >= 2 && st == stage) ? roomy + 1 : 0;
+            // inside a quarter of the window: one stage down still leaves 2x room, the trust stays
+            if (roomy >= 4 && stage > 13) { stage -= 1; roomy = 0; }
+        }
+        if (stage > (int)S - 1) stage = (int)S - 1;
+    }
+    int first_stage(uint32_t S) const { return (int)S - start_back < 13 ? 13 : (int)S - start_back; }
+    bool single_standby() const { return force_single || (stage && trusted >= 2 && seq - seen <= 2 * FLIGHT); }
+
     // The plan of this step's sort of n elements.  Returns false when the stand-by kernel reported a barrier time-out.
     bool plan(uint32_t n, SortPlan* out) {
         uint32_t S = 0;
@@ -79,31 +102,11 @@ struct SortPolicy {
         const volatile uint32_t* f = fb;
         const uint32_t s = f[0];
         if (s != seen) {
-            seen = s;
-            const int st = (int)f[1], cls = (int)f[3];
-            const bool passed = f[2] != FS_SORT_NO_PLAN;
             if (f[4]) return false;
-            if (stage == 0) stage = st;
-            if (s == skip_seq) {
-                // nothing to learn
-            } else if (!passed) {
-                if (st + 2 > stage) stage = st + 2;
-                trusted = 0; roomy = 0;
-            } else if (cls == 0) {
-                if (st + 1 > stage) stage = st + 1;     // a wider window is safer: the trust stays
-                trusted += 1; roomy = 0;
-            } else {
-                trusted += 1;
-                roomy = (cls >= 2 && st == stage) ? roomy + 1 : 0;
-                // inside a quarter of the window: one stage down still leaves 2x room, the trust stays
-                if (roomy >= 4 && stage > 13) { stage -= 1; roomy = 0; }
-            }
-            if (stage > (int)S - 1) stage = (int)S - 1;
+            observe(s, (int)f[1], f[2] != FS_SORT_NO_PLAN, (int)f[3], S);
         }
-        const int first = (int)S - start_back < 13 ? 13 : (int)S - start_back;
-        out->fuse_stage = stage ? stage : first;
-        out->fallback = (stage && trusted >= 2 && seq - seen <= 2 * FLIGHT) ? 1 : 0;
-        if (force_single) out->fallback = 1;
+        out->fuse_stage = stage ? stage : first_stage(S);
+        out->fallback = single_standby() ? 1 : 0;
         out->feedback = fb;
         out->seq = ++seq;
         return true;

@@ -404,6 +404,13 @@ int fs_constdiv_status(const fs_sim* sim);
  * the per-stage ones.  plan[0] / plan[1] (may be NULL): how often the device-side
  * certificate chose the shifted merge / the per-stage plan for this call (0, 0 when no plan was in play).  Blocking. */
 fs_status fs_selftest_sort(int device, uint64_t* pairs, uint32_t n, int fuse_stage, uint32_t plan[2]);
+/* The host policy that picks the sort's late-stage plan (csrc/sort_policy.h), replayed on the CPU against a model of the
+ * flow: `required[i]` is the lowest stage whose window the moves of step i fit (a stage more doubles the window); the
+ * certificate of step i, run at the stage the policy chose, passes iff stage >= required[i], fit class min(3, stage -
+ * required[i]); its report reaches the policy `lag` steps later (the engine keeps at most 4 steps in flight).
+ * Outputs per step: the stage chosen, 1 where the single stand-by launch was in the stream.  No device is touched. */
+fs_status fs_selftest_sort_policy(uint32_t log2_count, int start_back, uint32_t lag, const uint32_t* required, size_t steps,
+                                  uint32_t* stage_out, uint32_t* single_out);
 
 /* Diagnostics of the sort's late-stage plan (csrc/kernels_sort.hip): the network's last stages run as one shifted
  * merge when a device-side certificate allows it, as per-stage launches otherwise.  Counts since create.  Blocking. */
