@@ -130,6 +130,7 @@ struct fs_sim {
     uint32_t aos_tick = 0xFFFFFFFFu;   // tick whose state the AoS view holds (only meaningful with aos_live)
 
     fsd::ConstDiv div_2h3{}, div_h2{};   // exact constant divisions of the force pass, proven at create
+    fsd::ConstDiv div_h{};               // ... and of the cell coordinates (x / h), over the numerators clamped positions give
     bool rcp_ok = false, sqrt_ok = false; // rcp_rn_fast / sqrt_rn_fast proven on this device at create
 
     fsd::SortPolicy sortp;          // host side of the sort's late-stage plan (sort_policy.h)
@@ -265,6 +266,7 @@ fsd::StepParams make_params(const fs_sim& s) {
     P.fast_math = s.opts.math_mode == FS_MATH_WGSL_ULP ? 1 : s.opts.math_mode == FS_MATH_TOLERANCE ? 2 : 0;
     P.div_2h3 = s.div_2h3;
     P.div_h2 = s.div_h2;
+    P.div_h = s.div_h;
     // div_by_rcp's guards assume dst <= ~h <= 2^19 (fs_device.h); FS_NO_SHAREDIV=1 keeps every `/` a true division
     static const bool no_sharediv = getenv("FS_NO_SHAREDIV") != nullptr;
     // ... and the per-particle "safe operand" classification bounds the pressure numerators only if h * spiky <= 2^19
@@ -300,14 +302,16 @@ fsd::StepParams make_params_of_state(fs_sim& s) {
     return P;
 }
 
-fs_status prove_constdiv(hipStream_t st, uint32_t* scratch_word, float c, fsd::ConstDiv* out) {
+fs_status prove_constdiv(hipStream_t st, uint32_t* scratch_word, float c, fsd::ConstDiv* out, float hi = 0.0f) {
     out->c = c;
     out->y = 1.0f / c;
     out->ok = 0;
     if (!(c > 4.0f * FS_CONSTDIV_MIN) || !std::isfinite(c) || !std::isfinite(out->y) || getenv("FS_NO_CONSTDIV")) return FS_OK;
+    if (!(hi > 0.0f)) hi = c;                          // the force kernel's numerators: 2^-60 <= |x| <= c
+    if (!(hi < 0x1p40f) || !(hi >= FS_CONSTDIV_MIN)) return FS_OK;
     uint32_t bad = 1;
     FS_HIP(hipMemsetAsync(scratch_word, 0, sizeof(uint32_t), st));
-    fsd::launch_verify_constdiv(st, c, out->y, FS_CONSTDIV_MIN, c, scratch_word);   // the kernel's numerators: 2^-60 <= |x| <= c
+    fsd::launch_verify_constdiv(st, c, out->y, FS_CONSTDIV_MIN, hi, scratch_word);
     FS_HIP(hipMemcpyAsync(&bad, scratch_word, sizeof bad, hipMemcpyDeviceToHost, st));
     FS_HIP(hipStreamSynchronize(st));
     out->ok = bad == 0 ? 1 : 0;
@@ -320,6 +324,11 @@ fs_status prove_force_constants(fs_sim* s) {
     if (r != FS_OK) return r;
     r = prove_constdiv(s->stream, s->counter.p + 1, h * h, &s->div_h2);
     if (r != FS_OK) return r;
+    {   // cell coordinates: (clamped position + half the bounds) / h, numerators 0 .. 2 bs (host_uniform: bs = size / 2 - ...)
+        const float reach = 4.0f * fmaxf(fabsf(s->settings.size.x), fabsf(s->settings.size.y));
+        r = prove_constdiv(s->stream, s->counter.p + 1, h, &s->div_h, reach);
+        if (r != FS_OK) return r;
+    }
     // the lean reciprocal / square root of the shared-denominator path, over their whole ranges
     s->rcp_ok = s->sqrt_ok = false;
     if (getenv("FS_NO_SHAREDIV")) return FS_OK;
@@ -826,7 +835,7 @@ fs_status fs_sort_plan_read(fs_sim* s, fs_sort_plan_info* out) {
 
 /* Did the create-time proofs succeed for this handle's constants (2h^3, h^2)?  Bits 0 / 1. */
 int fs_constdiv_status(const fs_sim* s) {
-    return s ? (s->div_2h3.ok ? 1 : 0) | (s->div_h2.ok ? 2 : 0) | (s->rcp_ok ? 4 : 0) | (s->sqrt_ok ? 8 : 0) : 0;
+    return s ? (s->div_2h3.ok ? 1 : 0) | (s->div_h2.ok ? 2 : 0) | (s->rcp_ok ? 4 : 0) | (s->sqrt_ok ? 8 : 0) | (s->div_h.ok ? 16 : 0) : 0;
 }
 
 /* ------------------------------------------------- renderer hand-off without a host round trip */

@@ -40,6 +40,7 @@ struct StepParams {
     int32_t ref_quirks;
     int32_t fast_math;         // FS_MATH_WGSL_ULP: native rcp/sqrt in the force pass (not bit-exact)
     ConstDiv div_2h3, div_h2;  // the two constant denominators of funcs.wgsl:119 (2h^3, h^2)
+    ConstDiv div_h;            // the cell size of funcs.wgsl:212-214, proven over every numerator a clamped position can give
     int32_t share_div;         // force pass: one true division per denominator + div_by_rcp (bit-identical)
     // --- slab (multi-GPU) mode: the local grid is a window of global cell columns -------------
     int32_t col_origin;        // global column of local column 0 (0 on a single GPU)
@@ -74,10 +75,14 @@ __device__ __forceinline__ float2 predict_pos(const StepParams& P, float2 pos, f
     return pr;
 }
 
-// funcs.wgsl:212-214
+// funcs.wgsl:212-214.  The division by the cell size is the 3-instruction exact form when the create-time enumeration
+// proved it for every numerator in [2^-60, 4 max(bs_x, bs_y)] (engine.hip prove_force_constants): positions are clamped to
+// the bounds, so the numerators are 0 .. 2 bs; below 2^-60 both forms floor to 0, a NaN gives cell 0 either way.
+__device__ __forceinline__ float div_const_fast(float x, float c, float y);
 __device__ __forceinline__ void xy_of_point(const StepParams& P, float2 pt, uint32_t* cx, uint32_t* cy) {
-    const float fx = floorf(__fdiv_rn(pt.x + P.bs_x, P.h));
-    const float fy = floorf(__fdiv_rn(pt.y + P.bs_y, P.h));
+    const float nx = pt.x + P.bs_x, ny = pt.y + P.bs_y;
+    const float fx = floorf(P.div_h.ok ? div_const_fast(nx, P.h, P.div_h.y) : __fdiv_rn(nx, P.h));
+    const float fy = floorf(P.div_h.ok ? div_const_fast(ny, P.h, P.div_h.y) : __fdiv_rn(ny, P.h));
     *cx = f32_to_u32_sat(fx) + 1u;
     *cy = f32_to_u32_sat(fy) + 1u;
 }

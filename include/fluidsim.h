@@ -395,7 +395,8 @@ void fs_buffer_destroy(fs_buffer* buf);
  *    guards; operands outside the guards take the true division.
  * fs_selftest_constdiv exposes the first enumeration (mismatch count for constant c, reciprocal y,
  * range [lo, hi]); fs_constdiv_status returns bit 0 / 1 = proof succeeded for 2h^3 / h^2, bit 2 / 3
- * = for the lean reciprocal / square root (15 = everything in use). */
+ * = for the lean reciprocal / square root, bit 4 = for the cell size h of the cell-coordinate quotients (funcs.wgsl:212-214,
+ * numerators 2^-60 .. 4 x the larger bound) (31 = everything in use). */
 fs_status fs_selftest_constdiv(int device, float c, float y, float lo, float hi, uint32_t* mismatches);
 int fs_constdiv_status(const fs_sim* sim);
 /* The engine's sort (the reference network of sort.wgsl:27-51 on (key << 32 | index) pairs) run on `n` caller-supplied

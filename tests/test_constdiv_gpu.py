@@ -43,3 +43,9 @@ def test_constant_division_proofs(fs):
     assert bool(status & 2) == (results[(float(f(0.2)), "h2")] == 0)
     # bits 2 / 3: the lean reciprocal and square root were proven over their whole ranges on this device
     assert status & 4 and status & 8, f"rcp/sqrt proofs failed on this device (status {status})"
+    # bit 4: x / h of the cell coordinates (funcs.wgsl:212-214) for every numerator up to 4 x the larger bound —
+    # the same enumeration through the self-test entry point must agree
+    size = max(st.size.x, st.size.y)
+    h32 = f(st.smoothing_radius)
+    assert bool(status & 16) == (_mismatches(fs, float(h32), float(f(1.0) / h32), lo=2.0 ** -60, hi=float(f(4.0) * f(size))) == 0)
+    assert status & 16, "the default scene's cell size is expected to pass (h = 0.2)"
