@@ -112,7 +112,8 @@ struct fs_sim {
     DevArray<float2> pos, vel, pos_s, vel_s, pred;
     DevArray<float> rho;
     DevArray<float2> rho2;          // {density, RN(1/density)}: what the force pass gathers per neighbour
-    DevArray<uint32_t> key;
+    DevArray<uint32_t> key;         // keys of an uploaded / initial state; after a step they live in `pairs` (key_in_pairs)
+    bool key_in_pairs = false;
     DevArray<uint32_t> fdefer, fwork;   // force pass: per-block deferred-wave bits and the worklist (counter[3] = its length)
     DevArray<unsigned long long> safe;   // one bit per sorted particle: coordinates / velocity inside the exact-quotient ranges (fs_device.h)
     DevArray<fsd::u64> pairs;
@@ -396,7 +397,8 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
         fsd::launch_bitonic_sort(st, s->pairs.p, s->n, s->sort_dirty.p, &P, s->pos.p, s->vel.p, s->counter.p, &plan);
     }
     if (prof) FS_HIP(hipEventRecord(ev[2], st));
-    fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, s->key.p, s->cs.p,
+    s->key_in_pairs = true;        // the 4 B / particle of a second copy of the keys stay unwritten
+    fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, (uint32_t*)nullptr, s->cs.p,
                         s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, s->fdefer.p, s->counter.p + 4, counting);
     if (prof) FS_HIP(hipEventRecord(ev[3], st));
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
@@ -557,7 +559,8 @@ fs_status fs_particles_device(fs_sim* s, const fs_particle** out) {
     FS_HIP(hipSetDevice(s->device));
     if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
     if (!(s->aos_live && s->aos_tick == s->tick && s->tick != 0)) {   // live view: the force pass already wrote it
-        fsd::launch_export_aos(s->stream, s->n, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p, s->aos.p);
+        fsd::launch_export_aos(s->stream, s->n, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p, s->aos.p,
+                               s->key_in_pairs ? s->pairs.p : nullptr);
         FS_HIP(hipGetLastError());
         if (s->aos_live) s->aos_tick = s->tick;
     }
@@ -608,6 +611,10 @@ fs_status fs_upload_particles(fs_sim* s, const fs_particle* src, size_t n) {
     FS_HIP(hipSetDevice(s->device));
     if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
     if (n) FS_HIP(hipMemcpyAsync(s->aos.p, src, n * sizeof(fs_particle), hipMemcpyHostToDevice, s->stream));
+    if (s->key_in_pairs) {          // a partial upload keeps the other particles' keys: bring them home first
+        fsd::launch_keys_from_pairs(s->stream, s->n, s->pairs.p, s->key.p);
+        s->key_in_pairs = false;
+    }
     fsd::launch_import_aos(s->stream, (uint32_t)n, s->aos.p, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p);
     FS_HIP(hipStreamSynchronize(s->stream));
     s->aos_tick = 0xFFFFFFFFu;      // the live view (if any) no longer matches the state: re-materialise on demand

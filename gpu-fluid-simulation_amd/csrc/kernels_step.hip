@@ -62,7 +62,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
     vel_s[i] = v;
     const float2 pd = predict_pos(P, p, v);   // same expression as the key generation in the sort -> same bits
     pred_s[i] = pd;
-    key_s[i] = key;
+    if (key_s) key_s[i] = key;                // uniform; single-domain handles read the key back from `pairs` instead
     {   // fs_device.h "safe operand" classification (finished by k_density): one 64-bit word per wave
         const unsigned long long sb = __builtin_amdgcn_ballot_w64(kin_safe(pd, v));   // lanes that returned above: 0
         if ((threadIdx.x & 63u) == 0u) safe[i >> 6] = sb;
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
     // "safe operand" classification (fs_device.h) — negative sends every pair it takes part in to true divisions
     const float press = P.pressure_k * (rho - P.rest_density);  // the expression the force pass evaluates
     const bool ok = ((safe[i >> 6] >> (i & 63u)) & 1ull) != 0ull && rho <= FS_RCP_HI && fabsf(press) <= FS_PRESSURE_HI;
-    const float y = __fdiv_rn(1.0f, rho);
+    // rho >= 0.1; the lean reciprocal is proven correctly rounded on [2^-20, 2^20] (share_div implies that proof)
+    const float y = (P.share_div && rho <= FS_RCP_HI) ? rcp_rn_fast(rho) : __fdiv_rn(1.0f, rho);
     rho2_out[i] = make_float2(rho, ok ? y : -y);
 }
 
@@ -875,11 +876,13 @@ __global__ __launch_bounds__(FS_BLOCK) void k_export_aos(uint32_t n, const float
                                                          const float2* __restrict__ vel,
                                                          const float* __restrict__ rho,
                                                          const uint32_t* __restrict__ key,
+                                                         const u64* __restrict__ pairs,
                                                          AosParticle* __restrict__ out) {
     const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
     if (i >= n) return;
     AosParticle a;
-    a.position = pos[i]; a.predicted = pred[i]; a.velocity = vel[i]; a.density = rho[i]; a.grid = key[i];
+    a.position = pos[i]; a.predicted = pred[i]; a.velocity = vel[i]; a.density = rho[i];
+    a.grid = pairs ? (uint32_t)(pairs[i] >> 32) : key[i];     // after a step the sorted (key, source) pairs hold the keys
     out[i] = a;
 }
 
@@ -1070,10 +1073,18 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
 }
 
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
-                       const float* rho, const uint32_t* key, void* out) {
+                       const float* rho, const uint32_t* key, void* out, const u64* pairs) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_export_aos, dim3(nblk(n)), dim3(FS_BLOCK), 0, st, n, pos, pred, vel, rho, key,
+    hipLaunchKernelGGL(k_export_aos, dim3(nblk(n)), dim3(FS_BLOCK), 0, st, n, pos, pred, vel, rho, key, pairs,
                        (AosParticle*)out);
+}
+
+__global__ __launch_bounds__(FS_BLOCK) void k_keys_from_pairs(uint32_t n, const u64* __restrict__ pairs, uint32_t* __restrict__ key) {
+    const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i < n) key[i] = (uint32_t)(pairs[i] >> 32);
+}
+void launch_keys_from_pairs(hipStream_t st, uint32_t n, const u64* pairs, uint32_t* key) {
+    if (n) hipLaunchKernelGGL(k_keys_from_pairs, dim3(nblk(n)), dim3(FS_BLOCK), 0, st, n, pairs, key);
 }
 
 void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, float2* pred, float2* vel, float* rho,
