@@ -114,6 +114,7 @@ struct fs_sim {
     DevArray<float2> rho2;          // {density, RN(1/density)}: what the force pass gathers per neighbour
     DevArray<uint32_t> key;         // keys of an uploaded / initial state; after a step they live in `pairs` (key_in_pairs)
     bool key_in_pairs = false;
+    bool rho_in_rho2 = false;       // likewise the densities: rho2.x after a strict / ulp step, `rho` after an upload or a tolerance step
     DevArray<uint32_t> fdefer, fwork;   // force pass: per-block deferred-wave bits and the worklist (counter[3] = its length)
     DevArray<unsigned long long> safe;   // one bit per sorted particle: coordinates / velocity inside the exact-quotient ranges (fs_device.h)
     DevArray<fsd::u64> pairs;
@@ -401,7 +402,9 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, (uint32_t*)nullptr, s->cs.p,
                         s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, s->fdefer.p, s->counter.p + 4, counting);
     if (prof) FS_HIP(hipEventRecord(ev[3], st));
-    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
+    // strict / ulp modes: rho2.x IS the density; the separate 4-byte copy is only written in tolerance mode (rho2 = {P, 1/rho})
+    s->rho_in_rho2 = P.fast_math != 2;
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho_in_rho2 ? (float*)nullptr : s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, s->aos_live ? (void*)s->aos.p : nullptr, s->side, s->ev_fork, s->ev_join);
@@ -560,7 +563,7 @@ fs_status fs_particles_device(fs_sim* s, const fs_particle** out) {
     if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
     if (!(s->aos_live && s->aos_tick == s->tick && s->tick != 0)) {   // live view: the force pass already wrote it
         fsd::launch_export_aos(s->stream, s->n, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p, s->aos.p,
-                               s->key_in_pairs ? s->pairs.p : nullptr);
+                               s->key_in_pairs ? s->pairs.p : nullptr, s->rho_in_rho2 ? s->rho2.p : nullptr);
         FS_HIP(hipGetLastError());
         if (s->aos_live) s->aos_tick = s->tick;
     }
@@ -611,9 +614,10 @@ fs_status fs_upload_particles(fs_sim* s, const fs_particle* src, size_t n) {
     FS_HIP(hipSetDevice(s->device));
     if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
     if (n) FS_HIP(hipMemcpyAsync(s->aos.p, src, n * sizeof(fs_particle), hipMemcpyHostToDevice, s->stream));
-    if (s->key_in_pairs) {          // a partial upload keeps the other particles' keys: bring them home first
-        fsd::launch_keys_from_pairs(s->stream, s->n, s->pairs.p, s->key.p);
-        s->key_in_pairs = false;
+    if (s->key_in_pairs || s->rho_in_rho2) {   // a partial upload keeps the other particles' keys / densities: bring them home first
+        fsd::launch_keys_from_pairs(s->stream, s->n, s->key_in_pairs ? s->pairs.p : nullptr, s->key.p,
+                                    s->rho_in_rho2 ? s->rho2.p : nullptr, s->rho.p);
+        s->key_in_pairs = false; s->rho_in_rho2 = false;
     }
     fsd::launch_import_aos(s->stream, (uint32_t)n, s->aos.p, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p);
     FS_HIP(hipStreamSynchronize(s->stream));

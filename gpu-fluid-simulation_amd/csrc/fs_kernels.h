@@ -29,8 +29,10 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
 // pairs != nullptr: the keys are the high words of the sorted pairs (the state of the last step; launch_reorder with
 // key_s == nullptr does not store them a second time), else `key` (an uploaded state).
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
-                       const float* rho, const uint32_t* key, void* out, const u64* pairs = nullptr);
-void launch_keys_from_pairs(hipStream_t st, uint32_t n, const u64* pairs, uint32_t* key);   // key[i] = pairs[i] >> 32
+                       const float* rho, const uint32_t* key, void* out, const u64* pairs = nullptr,
+                       const float2* rho2 = nullptr /* != nullptr: densities are rho2[i].x (launch_density with rho == nullptr) */);
+// key[i] = pairs[i] >> 32 (pairs != nullptr), rho[i] = rho2[i].x (rho2 != nullptr): the copies the step no longer writes
+void launch_keys_from_pairs(hipStream_t st, uint32_t n, const u64* pairs, uint32_t* key, const float2* rho2, float* rho);
 void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, float2* pred, float2* vel, float* rho,
                        uint32_t* key);
 void launch_render_density(hipStream_t st, const StepParams& P, float2 wmin, float2 wmax, uint32_t width,

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
     }
     rho = fmaxf(rho, 1.19209290e-07f);                          // funcs.wgsl:202
     rho = fmaxf(rho, 0.1f);                                     // compute.wgsl:70
-    rho_out[i] = rho;
+    if (rho_out) rho_out[i] = rho;                              // uniform; single-domain handles read it back from rho2.x
     // {rho, +-RN(1/rho)}: the force pass divides by neighbours' densities; the sign carries the particle's
     // "safe operand" classification (fs_device.h) — negative sends every pair it takes part in to true divisions
     const float press = P.pressure_k * (rho - P.rest_density);  // the expression the force pass evaluates
@@ -877,11 +877,12 @@ __global__ __launch_bounds__(FS_BLOCK) void k_export_aos(uint32_t n, const float
                                                          const float* __restrict__ rho,
                                                          const uint32_t* __restrict__ key,
                                                          const u64* __restrict__ pairs,
+                                                         const float2* __restrict__ rho2,
                                                          AosParticle* __restrict__ out) {
     const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
     if (i >= n) return;
     AosParticle a;
-    a.position = pos[i]; a.predicted = pred[i]; a.velocity = vel[i]; a.density = rho[i];
+    a.position = pos[i]; a.predicted = pred[i]; a.velocity = vel[i]; a.density = rho2 ? rho2[i].x : rho[i];
     a.grid = pairs ? (uint32_t)(pairs[i] >> 32) : key[i];     // after a step the sorted (key, source) pairs hold the keys
     out[i] = a;
 }
@@ -1073,18 +1074,21 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
 }
 
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
-                       const float* rho, const uint32_t* key, void* out, const u64* pairs) {
+                       const float* rho, const uint32_t* key, void* out, const u64* pairs, const float2* rho2) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_export_aos, dim3(nblk(n)), dim3(FS_BLOCK), 0, st, n, pos, pred, vel, rho, key, pairs,
+    hipLaunchKernelGGL(k_export_aos, dim3(nblk(n)), dim3(FS_BLOCK), 0, st, n, pos, pred, vel, rho, key, pairs, rho2,
                        (AosParticle*)out);
 }
 
-__global__ __launch_bounds__(FS_BLOCK) void k_keys_from_pairs(uint32_t n, const u64* __restrict__ pairs, uint32_t* __restrict__ key) {
+__global__ __launch_bounds__(FS_BLOCK) void k_keys_from_pairs(uint32_t n, const u64* __restrict__ pairs, uint32_t* __restrict__ key,
+                                                              const float2* __restrict__ rho2, float* __restrict__ rho) {
     const uint32_t i = blockIdx.x * FS_BLOCK + threadIdx.x;
-    if (i < n) key[i] = (uint32_t)(pairs[i] >> 32);
+    if (i >= n) return;
+    if (pairs) key[i] = (uint32_t)(pairs[i] >> 32);
+    if (rho2) rho[i] = rho2[i].x;
 }
-void launch_keys_from_pairs(hipStream_t st, uint32_t n, const u64* pairs, uint32_t* key) {
-    if (n) hipLaunchKernelGGL(k_keys_from_pairs, dim3(nblk(n)), dim3(FS_BLOCK), 0, st, n, pairs, key);
+void launch_keys_from_pairs(hipStream_t st, uint32_t n, const u64* pairs, uint32_t* key, const float2* rho2, float* rho) {
+    if (n) hipLaunchKernelGGL(k_keys_from_pairs, dim3(nblk(n)), dim3(FS_BLOCK), 0, st, n, pairs, key, rho2, rho);
 }
 
 void launch_import_aos(hipStream_t st, uint32_t n, const void* in, float2* pos, float2* pred, float2* vel, float* rho,
