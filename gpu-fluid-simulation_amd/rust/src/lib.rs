@@ -43,6 +43,8 @@ extern "C" {
     fn fs_upload_force_field(sim: *mut fs_sim, field: *const Vec2, w: u32, h: u32) -> c_int;
     fn fs_download_particles(sim: *mut fs_sim, dst: *mut ParticleInstance, n: usize) -> c_int;
     fn fs_last_error() -> *const c_char;
+    /// diagnostics of the sort's late-stage plan (include/fluidsim.h fs_sort_plan_info): six u32 counters
+    fn fs_sort_plan_read(sim: *mut fs_sim, out: *mut [u32; 6]) -> c_int;
     // hand-off without a host round trip (include/fluidsim.h: fs_export_handle)
     fn fs_export_handle(sim: *mut fs_sim, which: c_int, out: *mut MemHandle) -> c_int;
     // native RCCL transport for a multi-GPU host (include/fluidsim.h: fs_comm_*, fs_slab_exchange)
