@@ -242,9 +242,9 @@ def main():
     # roofline: the SAME window once more on a fresh handle, now with a HIP event at every pass boundary
     # (they serialise the kernel boundaries and cost ~1 %, which is why the headline window runs without them)
     ms_profiled, per_pass = run_window(make_sim, tick, args.warmup, args.steps, n, alg_bytes)
-    # the dominant KERNEL: a pass's time x the share its largest kernel has of it (the sort pass is ~37 launches, the
-    # largest ~27 % of it; the force pass is the lean kernel + the general one, profiles/r02_f_kernel_stats.csv)
-    share = {"sort": 0.33, "force": 0.94, "density": 1.0, "reorder": 0.97, "predict_key": 1.0}
+    # the dominant KERNEL: a pass's time x the share its largest kernel has of it (the sort pass is ~16 launches, the
+    # largest ~41 % of it; the force pass is the lean kernel + the general one, profiles/r02_h_kernel_stats.csv)
+    share = {"sort": 0.41, "force": 0.94, "density": 1.0, "reorder": 0.97, "predict_key": 1.0}
     dom = max(per_pass, key=lambda k: per_pass[k]["ms"] * share.get(k, 1.0))
 
     traffic, traffic_src = args.pmc_traffic, "--pmc-traffic argument (separate rocprofv3 --pmc run of this command)"
