@@ -188,6 +188,31 @@ def test_nan_reset_speed_clamp_and_walls(fs, orc):
     run_and_compare(sim, ref, tick, 4, "nan/clamp")
 
 
+@pytest.mark.parametrize("math_mode", ["ieee", "tolerance"])
+def test_partial_upload_after_steps_keeps_the_rest(fs, math_mode):
+    """A step no longer writes separate copies of the keys / densities (they live in the sorted pairs and in the force
+    pass's {rho, 1/rho} array); an upload of the first k records must still leave the other records' keys and
+    densities as the last step produced them (ResizableBuffer::write semantics, src/buffer.rs:61-87)."""
+    n, k = 8192, 1000
+    st, off, tick = fs.dam_break_2d(n)
+    mm = fs.FS_MATH_IEEE if math_mode == "ieee" else fs.FS_MATH_TOLERANCE
+    sim = fs.FluidSimulation(st, device=0, initial_offset=off, math_mode=mm)
+    for _ in range(5):
+        sim.tick(tick)
+    before = sim.download_particles()
+    assert before["density"].min() > 0 and np.all(before["grid"][:-1] <= before["grid"][1:])
+    rng = np.random.default_rng(3)
+    head = before[:k].copy()
+    head["density"] = rng.uniform(1, 2, size=k).astype(np.float32)
+    head["grid"] = rng.integers(0, 2**32, size=k, dtype=np.uint32)
+    sim.upload_particles(head)
+    after = sim.download_particles()
+    assert np.array_equal(after[:k].view(np.uint8), head.view(np.uint8))
+    assert np.array_equal(after[k:].view(np.uint8), before[k:].view(np.uint8))
+    sim.tick(tick)                                   # and the engine carries on from the mixed state
+    assert np.isfinite(sim.download_particles()["position"]).all()
+
+
 def test_upload_download_roundtrip(fs):
     st, off, tick = fs.dam_break_2d(4096)
     sim = fs.FluidSimulation(st, device=0, initial_offset=off)
