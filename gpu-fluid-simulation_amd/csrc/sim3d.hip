@@ -73,7 +73,15 @@ __global__ __launch_bounds__(B3) void k3_reorder(Params3 P, const u64* __restric
     const u64 pr = pairs[i];
     const uint32_t key = (uint32_t)(pr >> 32), src = (uint32_t)pr;
     const float4 p = pos_in[src], v = vel_in[src];
-    pos_s[i] = p; vel_s[i] = v; pred[i] = predict3(P, p, v); key_s[i] = key;
+    const float4 pd = predict3(P, p, v);
+    // "safe operand" classification, kinematic part (fs_device.h): coordinates and velocity components 0 or >= 2^-53,
+    // |v| <= 2^59 — carried as the sign of vel_s.w (the lane is free: a velocity has three components); k3_density
+    // finishes it with the density / pressure bounds and leaves +-RN(1/rho) there for the force pass
+    const bool ksafe = lo_safe(pd.x) && lo_safe(pd.y) && lo_safe(pd.z) && lo_safe(v.x) && lo_safe(v.y) && lo_safe(v.z) &&
+                       fabsf(v.x) <= 0x1p59f && fabsf(v.y) <= 0x1p59f && fabsf(v.z) <= 0x1p59f;
+    float4 vs = v;
+    vs.w = ksafe ? 1.0f : -1.0f;
+    pos_s[i] = p; vel_s[i] = vs; pred[i] = pd; key_s[i] = key;
     const uint32_t kc = key < P.ncell ? key : P.ncell;
     if (i == 0) {
         fill_cells(cs, 0u, kc + 1u, 0u, work, counter, work_cap);
@@ -110,7 +118,8 @@ __device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
 
 // The 27-cell sweep runs plane by plane (z outer): per plane the workgroup's three row ranges are
 // staged into LDS with coalesced loads (fs_device.h block_tile_bounds), the lanes loop over LDS.
-__global__ __launch_bounds__(B3) void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs) {
+__global__ __launch_bounds__(B3) void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs,
+                                                 float4* __restrict__ vel_s) {
     __shared__ float4 s_pred[3][TILE3];
     __shared__ uint32_t s_red[24];
     const uint32_t i = blockIdx.x * B3 + threadIdx.x;
@@ -161,7 +170,16 @@ __global__ __launch_bounds__(B3) void k3_density(Params3 P, float4* __restrict__
     }
     if (!live) return;
     rho = fmaxf(rho, 1.19209290e-07f);
-    reinterpret_cast<float*>(pred + i)[3] = fmaxf(rho, 0.1f);      // pred.w <- density (other lanes read .xyz only)
+    rho = fmaxf(rho, 0.1f);
+    reinterpret_cast<float*>(pred + i)[3] = rho;                   // pred.w <- density (other lanes read .xyz only)
+    // vel_s.w <- +-RN(1/rho): what the force pass divides by, once per particle instead of once per pair; positive only
+    // when every operand this particle brings to a pair is inside the proven quotient ranges (fs_device.h)
+    float* yw = reinterpret_cast<float*>(vel_s + i) + 3;
+    const bool ksafe = *yw > 0.0f;
+    const float press = P.pressure_k * (rho - P.rest_density);     // the expression the force pass evaluates
+    const bool ok = ksafe && rho <= FS_RCP_HI && fabsf(press) <= FS_PRESSURE_HI;
+    const float y = (P.share_div && rho <= FS_RCP_HI) ? rcp_rn_fast(rho) : __fdiv_rn(1.0f, rho);
+    *yw = ok ? y : -y;
 }
 
 struct Acc3 { float px, py, pz, vx, vy, vz; uint32_t seed; };
@@ -215,16 +233,17 @@ __device__ __forceinline__ Terms3 terms3(const Params3& P, float4 me, float4 mv,
 // the ten quotients — bit-identical to terms3() for every lane whose bit stays set in `good`
 // (fs_device.h: the proven ranges).  No PRNG / tiny-distance path: those lanes clear their bit and
 // the caller re-evaluates the pair with terms3() for the whole wave.
+__device__ __forceinline__ wave_mask num_lo_ok3(float a) { return wm(fabsf(a) >= 0x1p-76f) | wm(a == 0.0f); }   // NaN: 0
 __device__ __forceinline__ Terms3 terms3_shared(const Params3& P, float4 me, float4 mv, float pressure, float4 q,
                                                 float4 nv, wave_mask& good) {
     const float h = P.h;
     const float ox = q.x - me.x, oy = q.y - me.y, oz = q.z - me.z;
     const float r2 = ox * ox + oy * oy + oz * oz;
     const float nrho = q.w;                                            // >= 0.1 (k3_density)
-    good = wm(r2 >= FS_SQRT_LO) & rcp_num_lo_ok(ox) & rcp_num_lo_ok(oy) & rcp_num_lo_ok(oz) & wm(nrho <= FS_RCP_HI);
+    const float yrho = nv.w;                                           // +-RN(1/nrho): the sign is the neighbour's classification
+    good = wm(r2 >= FS_SQRT_LO) & wm(yrho > 0.0f);
     const float dst = sqrt_rn_fast(r2);                                // r2 <= h*h: the scan admitted it
     const float ydst = rcp_rn_fast(dst);
-    const float yrho = rcp_rn_fast(nrho);
     const float dx = div_by_rcp(ox, dst, ydst), dy = div_by_rcp(oy, dst, ydst), dz = div_by_rcp(oz, dst, ydst);
     const float npress = P.pressure_k * (nrho - P.rest_density);
     const bool inside = dst <= h;
@@ -232,7 +251,9 @@ __device__ __forceinline__ Terms3 terms3_shared(const Params3& P, float4 me, flo
     const float shared = (pressure + npress) * 0.5f;
     const float apx = dx * kern * shared, apy = dy * kern * shared, apz = dz * kern * shared;
     const float dvx = nv.x - mv.x, dvy = nv.y - mv.y, dvz = nv.z - mv.z;
-    good &= rcp_num_ok(apx) & rcp_num_ok(apy) & rcp_num_ok(apz) & rcp_num_ok(dvx) & rcp_num_ok(dvy) & rcp_num_ok(dvz);
+    // both particles safe => every numerator is 0 or in [2^-76, 2^60] except the lower bound of the three pressure
+    // numerators (a product of three factors can be tiny without any factor being unusual)
+    good &= num_lo_ok3(apx) & num_lo_ok3(apy) & num_lo_ok3(apz);
     const float a = div_const_fast(-(dst * dst * dst), P.div_2h3.c, P.div_2h3.y);   // share_div implies both proofs
     const float b = div_const_fast(dst * dst, P.div_h2.c, P.div_h2.y);
     const float hq = div_by_rcp(h, 2.0f * dst, 0.5f * ydst);
@@ -251,7 +272,7 @@ __device__ __forceinline__ Terms3 pair3(const Params3& P, float4 me, float4 mv, 
                                         Acc3& A) {
     wave_mask good = 0;
     Terms3 T;
-    if (P.share_div) T = terms3_shared(P, me, mv, pressure, q, nv, good);
+    if (P.share_div) { T = terms3_shared(P, me, mv, pressure, q, nv, good); good &= wm(mv.w > 0.0f); }   // + the lane's own classification
     if (good != wm(true)) T = terms3(P, me, mv, pressure, q, nv, A.seed);      // rare, wave-uniform
     return T;
 }
@@ -602,7 +623,8 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     P.frame = s->tick;
     P.div_2h3 = s->div_2h3;
     P.div_h2 = s->div_h2;
-    P.share_div = s->share_div ? 1 : 0;
+    // the classification bounds the pressure numerators by (1 + 2^-22) h spiky 2^39 <= 2^60 (fs_device.h)
+    P.share_div = (s->share_div && h * P.spiky <= FS_HSPIKY_HI) ? 1 : 0;
     hipStream_t st = s->stream;
     hipEvent_t* ev = nullptr;
     if (s->profile) {
@@ -623,7 +645,7 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
                        s->pred.p, s->key.p, s->cs.p, (GapEntry*)s->work.p, s->counter.p, s->work_cap);
     launch_fill_gaps(st, s->cs.p, s->work.p, s->counter.p, s->work_cap);
     if (ev) H3(hipEventRecord(ev[3], st));
-    hipLaunchKernelGGL(k3_density, grid, block, 0, st, P, s->pred.p, s->cs.p);
+    hipLaunchKernelGGL(k3_density, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p);
     if (ev) H3(hipEventRecord(ev[4], st));
     hipLaunchKernelGGL(k3_force, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p);
     if (ev) { H3(hipEventRecord(ev[5], st)); s->pending += 1; }
