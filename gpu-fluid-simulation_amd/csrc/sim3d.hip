@@ -280,7 +280,7 @@ __device__ __forceinline__ Terms3 pair3(const Params3& P, float4 me, float4 mv, 
 // (the general sweep, sweep3_chunks, follows the mask sweep below: it shares its helpers)
 
 #ifndef FS3_FORCE_WAVES
-#define FS3_FORCE_WAVES 5   // measured (8 M): 4 (allocator's choice, 115 VGPRs), 5, 6 waves/SIMD -> see DESIGN.md §6
+#define FS3_FORCE_WAVES 6   // measured (8 M, steps 10-110, after the safe-operand classification): 4: 2.265, 5: 2.232, 6: 2.215 ms
 #endif
 #define TILE3_PAD 64u
 #define TILE3_ROW (TILE3 + TILE3_PAD)
