@@ -407,7 +407,8 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho_in_rho2 ? (float*)nullptr : s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, s->aos_live ? (void*)s->aos.p : nullptr, s->side, s->ev_fork, s->ev_join);
+                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, s->aos_live ? (void*)s->aos.p : nullptr, s->side, s->ev_fork, s->ev_join,
+                      s->sortp.general_grid(), s->sortp.general_hint());
     if (s->aos_live) s->aos_tick = s->tick;
     if (prof) {
         FS_HIP(hipEventRecord(ev[5], st));
@@ -970,6 +971,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
         FS_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         FS_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     }
+    FS_TRY(s->sortp.init(8));   // slab handles use the pinned words for the force pass's work report only (sort: per-stage plan)
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
     FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc((cap + 63) / 64 + 1)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
@@ -1095,7 +1097,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     if (ev) FS_HIP(hipEventRecord(ev[4], st));
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
-                      s->ev_fork, s->ev_join);
+                      s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint());
     if (ev) { FS_HIP(hipEventRecord(ev[5], st)); s->prof_pending += 1; }
     FS_HIP(hipGetLastError());
     s->slab_packed = false;

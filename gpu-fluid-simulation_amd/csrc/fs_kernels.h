@@ -25,7 +25,9 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
                   uint32_t* worklist /* per block */, uint32_t* work_count,
                   void* aos_out = nullptr /* 32-B ParticleInstance records, or none */,
                   hipStream_t side = nullptr /* second stream: the pre-registered general work runs beside the lean kernel */,
-                  hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
+                  hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr,
+                  uint32_t general_grid = 0 /* workgroups of the general kernel; 0: the full grid */,
+                  uint32_t* general_hint = nullptr /* host-visible word: entries the general kernel found in its lists */);
 // pairs != nullptr: the keys are the high words of the sorted pairs (the state of the last step; launch_reorder with
 // key_s == nullptr does not store them a second time), else `key` (an uploaded state).
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,

@@ -851,10 +851,13 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
 #define FS_GENERAL_WAVES 5
 #endif
 template <int MODE, bool AOS>
-__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_GENERAL_WAVES, FS_GENERAL_WAVES))) void k_force_general(FS_FORCE_ARGS, uint32_t which) {
+__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_GENERAL_WAVES, FS_GENERAL_WAVES))) void k_force_general(FS_FORCE_ARGS, uint32_t which, uint32_t* __restrict__ hint) {
     __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
+    // how much work the lists held: the host sizes the next steps' grid of this kernel from it (a few steps late,
+    // through pinned memory; an idle launch costs what its workgroups cost to come and go)
+    if (hint && blockIdx.x == 0 && threadIdx.x == 0) *hint = which == 2u ? work_count[0] + work_count[1] : work_count[which];
     // which = 0 / 1: one list; which = 2: the pre-registered list, then the late one (the usual single follow-up launch)
     for (uint32_t w = (which == 2u ? 0u : which); w <= (which == 2u ? 1u : which); ++w) {
         const uint32_t count = work_count[w];        // written earlier in the stream (k_density / the lean kernel)
@@ -1041,33 +1044,35 @@ void launch_density(hipStream_t st, const StepParams& P, const float2* pred, con
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out, const float* rho_arr, uint32_t* defer_bits, uint32_t* worklist,
-                  uint32_t* work_count, void* aos_out, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
+                  uint32_t* work_count, void* aos_out, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
+                  uint32_t general_grid, uint32_t* general_hint) {
     const uint32_t nb = nblk(P.n), grid = xcd_grid(nb, P.xcd_chunk_log2);
-#define FS_LAUNCH_FORCE(K, M, A, G, S, W)                                                                           \
+#define FS_LAUNCH_FORCE(K, M, A, G, S, ...)                                                                         \
     hipLaunchKernelGGL((K<M, A>), dim3(G), dim3(FS_BLOCK), 0, S, P, pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex, \
-                       pos_out, vel_out, (AosParticle*)aos_out, rho_arr, defer_bits, worklist, work_count, W)
-#define FS_LAUNCH_FORCE_MODE(K, G, S, W)                                                                            \
+                       pos_out, vel_out, (AosParticle*)aos_out, rho_arr, defer_bits, worklist, work_count, __VA_ARGS__)
+#define FS_LAUNCH_FORCE_MODE(K, G, S, ...)                                                                          \
     do {                                                                                                            \
-        if (P.fast_math == 2) { if (aos_out) FS_LAUNCH_FORCE(K, 2, true, G, S, W); else FS_LAUNCH_FORCE(K, 2, false, G, S, W); } \
-        else if (P.fast_math == 1) { if (aos_out) FS_LAUNCH_FORCE(K, 1, true, G, S, W); else FS_LAUNCH_FORCE(K, 1, false, G, S, W); } \
-        else { if (aos_out) FS_LAUNCH_FORCE(K, 0, true, G, S, W); else FS_LAUNCH_FORCE(K, 0, false, G, S, W); }      \
+        if (P.fast_math == 2) { if (aos_out) FS_LAUNCH_FORCE(K, 2, true, G, S, __VA_ARGS__); else FS_LAUNCH_FORCE(K, 2, false, G, S, __VA_ARGS__); } \
+        else if (P.fast_math == 1) { if (aos_out) FS_LAUNCH_FORCE(K, 1, true, G, S, __VA_ARGS__); else FS_LAUNCH_FORCE(K, 1, false, G, S, __VA_ARGS__); } \
+        else { if (aos_out) FS_LAUNCH_FORCE(K, 0, true, G, S, __VA_ARGS__); else FS_LAUNCH_FORCE(K, 0, false, G, S, __VA_ARGS__); }      \
     } while (0)
 #ifndef FS_GENERAL_GRID
 #define FS_GENERAL_GRID 4096u   // 16M, steps 150-250: force 1.175 (1024) -> 1.126 (2048) -> 1.117 ms (4096); steps 10-110 unchanged
 #endif
-    const uint32_t gg = nb < FS_GENERAL_GRID ? nb : FS_GENERAL_GRID;
+    uint32_t gg = general_grid ? general_grid : FS_GENERAL_GRID;      // the host's choice (engine.hip), else the full grid
+    if (gg > nb) gg = nb;
     if (side) {   // fork: the pre-registered waves on the second stream, beside the lean kernel
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
-        FS_LAUNCH_FORCE_MODE(k_force_general, gg, side, 0u);
+        FS_LAUNCH_FORCE_MODE(k_force_general, gg, side, 0u, (uint32_t*)nullptr);
         (void)hipEventRecord(ev_join, side);
     }
     FS_LAUNCH_FORCE_MODE(k_force, grid, st, 0u);
     if (side) {
         (void)hipStreamWaitEvent(st, ev_join, 0);
-        FS_LAUNCH_FORCE_MODE(k_force_general, (nb < 256u ? nb : 256u), st, 1u);
+        FS_LAUNCH_FORCE_MODE(k_force_general, (nb < 256u ? nb : 256u), st, 1u, (uint32_t*)nullptr);
     } else {
-        FS_LAUNCH_FORCE_MODE(k_force_general, gg, st, 2u);      // both lists in one follow-up launch
+        FS_LAUNCH_FORCE_MODE(k_force_general, gg, st, 2u, general_hint);      // both lists in one follow-up launch
     }
 #undef FS_LAUNCH_FORCE_MODE
 #undef FS_LAUNCH_FORCE

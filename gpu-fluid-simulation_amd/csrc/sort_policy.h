@@ -44,7 +44,7 @@ struct SortPolicy {
         if (fx) fixed_stage = atoi(fx);
         force_single = tr && atoi(tr) != 0;
         enabled = !(e && atoi(e) == 0) && !fx;
-        if (!enabled) return hipSuccess;
+        // the words are allocated even when the plan policy is off: fb[6] is the force pass's work report (general_grid())
         hipError_t r = hipHostMalloc((void**)&fb, 8 * sizeof(uint32_t), hipHostMallocMapped);
         if (r == hipSuccess) memset(fb, 0, 8 * sizeof(uint32_t));
         return r;
@@ -92,6 +92,16 @@ struct SortPolicy {
     }
     int first_stage(uint32_t S) const { return (int)S - start_back < 13 ? 13 : (int)S - start_back; }
     bool single_standby() const { return force_single || (stage && trusted >= 2 && seq - seen <= 2 * FLIGHT); }
+
+    // Workgroups for the force pass's general kernel (k_force_general) from its own report of a few steps ago: an idle
+    // launch costs what its workgroups cost to come and go (16M: ~13 us with 1024, ~25 us with 4096), a busy one wants
+    // them all (dense floor: force 1.175 ms with 1024, 1.117 with 4096).  Performance only.
+    uint32_t general_grid() const {
+        if (!fb) return 0;
+        const uint32_t entries = ((const volatile uint32_t*)fb)[6];
+        return entries == 0 ? 256u : entries < 128u ? 1024u : 4096u;
+    }
+    uint32_t* general_hint() const { return fb ? fb + 6 : nullptr; }
 
     // The plan of this step's sort of n elements.  Returns false when the stand-by kernel reported a barrier time-out.
     bool plan(uint32_t n, SortPlan* out) {
