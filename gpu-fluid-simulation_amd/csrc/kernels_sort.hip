@@ -32,18 +32,26 @@ namespace fsd {
 // re-distributed through LDS between groups (instead of one LDS round trip per step).  Layout of group g (in-thread
 // bits [g GB, (g+1) GB), B = g GB):   idx = (t >> B) << (B + GB) | r << B | t & (2^B - 1)
 // — the top group is also the coalesced global layout (idx = r << (12-GB) | t), group 0 holds E contiguous elements.
-//   GB = 4: 256 threads x 16 elements, three groups — the default;
+//   GB = 4: 256 threads x 16 elements, three groups — for sorts of more than 512 tiles;
 //   GB = 3: 512 threads x  8 elements, four groups: twice the waves per tile (the tile's LDS footprint bounds the
 //           occupancy: four tiles per CU) for a third more LDS round trips.  Measured at 16M: first kernel 179 -> 190 us,
-//           tails equal, stage 12 42 -> 38 us, sort 0.435 -> 0.445 ms: not the default (-DFS_SORT_GB=3 builds it).
+//           tails equal, stage 12 42 -> 38 us, sort 0.435 -> 0.445 ms.  Few tiles cannot fill the chip (1M particles: 256
+//           tiles on 256 CUs) and there the shorter per-thread chains win: sort_gb().
 // LDS addresses are padded (lt_pad) so that the 8-byte accesses of all layouts are bank-conflict free, or 2-way at
 // worst (64 x 4-B banks; GB = 3: chosen by enumeration over the layouts and their mirrored reads).
 // The mirror step of stage s is done as in k_bitonic_strided: rows with bit s set are read
 // from idx ^ (2^s - 1), after which it is a plain distance-2^s step and the remaining steps
 // of that round compare in reversed order on those rows.
-#ifndef FS_SORT_GB
-#define FS_SORT_GB 4
-#endif
+// Elements per thread of the tile kernels, chosen per sort from the tile count (both forms are compiled): FS_SORT_GB in
+// the environment pins one.
+static int sort_gb(uint32_t tiles) {
+    static const int env = [] { const char* e = getenv("FS_SORT_GB"); return e ? atoi(e) : 0; }();
+    static const uint32_t small = [] { const char* e = getenv("FS_SORT_GB3_TILES"); return e ? (uint32_t)atoi(e) : 512u; }();
+    if (env == 3 || env == 4) return env;
+    // few tiles cannot fill the chip: shorter per-thread chains win there.  Sort pass, ms, 8 / 16 elements per thread:
+    // 1M (256 tiles) 0.066 / 0.078, 2M 0.094 / 0.098, 4M 0.142 / 0.136, 8M 0.253 / 0.250, 16M 0.445 / 0.435
+    return tiles <= small ? 3 : 4;
+}
 template <int GB> struct LT {
     static constexpr int E = 1 << GB;                     // elements per thread
     static constexpr int THREADS = (int)SORT_T >> GB;
@@ -673,8 +681,12 @@ static int launch_stage(hipStream_t st, u64* pairs, uint32_t n, uint32_t p2, uin
     }
     StepParams P0;
     memset(&P0, 0, sizeof P0);
-    hipLaunchKernelGGL((k_bitonic_local<false, false, FS_SORT_GB>), dim3(tiles), dim3(LT<FS_SORT_GB>::THREADS), 0, st, pairs, n, 0u, dirty, P0,
-                       (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr, gate, glo, ghi);
+    if (sort_gb(tiles) == 3)
+        hipLaunchKernelGGL((k_bitonic_local<false, false, 3>), dim3(tiles), dim3(LT<3>::THREADS), 0, st, pairs, n, 0u, dirty, P0,
+                           (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr, gate, glo, ghi);
+    else
+        hipLaunchKernelGGL((k_bitonic_local<false, false, 4>), dim3(tiles), dim3(LT<4>::THREADS), 0, st, pairs, n, 0u, dirty, P0,
+                           (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr, gate, glo, ghi);
     return launches + 1;
 }
 
@@ -690,13 +702,14 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
     const uint32_t init_stages = S < SORT_LOG_T ? S : SORT_LOG_T;
     StepParams P0;
     memset(&P0, 0, sizeof P0);
-    if (keygen)
-        hipLaunchKernelGGL((k_bitonic_local<true, true, FS_SORT_GB>), dim3(tiles), dim3(LT<FS_SORT_GB>::THREADS), 0, st, pairs, n, init_stages,
-                           dirty, *keygen, pos, vel, gap_counter, (const uint32_t*)nullptr, 0u);
-    else
-        hipLaunchKernelGGL((k_bitonic_local<true, false, FS_SORT_GB>), dim3(tiles), dim3(LT<FS_SORT_GB>::THREADS), 0, st, pairs, n,
-                           init_stages, dirty, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, 0u);
+    const int gb = sort_gb(tiles);
+#define FS_LAUNCH_INIT(KG, GBV, PP, POS, VEL, GC)                                                                      \
+    hipLaunchKernelGGL((k_bitonic_local<true, KG, GBV>), dim3(tiles), dim3(LT<GBV>::THREADS), 0, st, pairs, n, init_stages, \
+                       dirty, PP, POS, VEL, GC, (const uint32_t*)nullptr, 0u, 0u)
+    if (keygen) { if (gb == 3) FS_LAUNCH_INIT(true, 3, *keygen, pos, vel, gap_counter); else FS_LAUNCH_INIT(true, 4, *keygen, pos, vel, gap_counter); }
+    else if (gb == 3) FS_LAUNCH_INIT(false, 3, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
+    else FS_LAUNCH_INIT(false, 4, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
+#undef FS_LAUNCH_INIT
     ++launches;                                         // leaves every tile sorted and its flag cleared
     const int skip_from = sort_skip_stage();
     const int mmax_early = sort_mmax(), mmax_late = sort_mmax_late(), late_from = sort_late_stage();
@@ -733,7 +746,8 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
         // a stage at or after the verdict's is already done: these launches then return at once (~5 us each)
         const bool gated = s0 && stage >= s0;
         if (stage == SORT_LOG_T && fused12) {          // (never gated: s0 > SORT_LOG_T)
-            hipLaunchKernelGGL((k_bitonic_stage12<FS_SORT_GB>), dim3((tiles + 1u) / 2u), dim3(LT<FS_SORT_GB>::THREADS), 0, st, pairs, n);
+            if (gb == 3) hipLaunchKernelGGL((k_bitonic_stage12<3>), dim3((tiles + 1u) / 2u), dim3(LT<3>::THREADS), 0, st, pairs, n);
+            else hipLaunchKernelGGL((k_bitonic_stage12<4>), dim3((tiles + 1u) / 2u), dim3(LT<4>::THREADS), 0, st, pairs, n);
             ++launches;
             continue;
         }
