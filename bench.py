@@ -243,7 +243,7 @@ def main():
     # (they serialise the kernel boundaries and cost ~1 %, which is why the headline window runs without them)
     ms_profiled, per_pass = run_window(make_sim, tick, args.warmup, args.steps, n, alg_bytes)
     # the dominant KERNEL: a pass's time x the share its largest kernel has of it (the sort pass is ~16 launches, the
-    # largest ~41 % of it; the force pass is the lean kernel + the general one, profiles/r02_j_kernel_stats.csv)
+    # largest ~41 % of it; the force pass is the lean kernel + the general one, profiles/r02_k_kernel_stats.csv)
     share = {"sort": 0.41, "force": 0.94, "density": 1.0, "reorder": 0.97, "predict_key": 1.0}
     dom = max(per_pass, key=lambda k: per_pass[k]["ms"] * share.get(k, 1.0))
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 validation campaigns on the final code: long runs against the oracle, fuzz of parity / API / slabs
 set -o pipefail
-O=gpurun_out/r02j; mkdir -p $O
+O=gpurun_out/r02k; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build_product(); g.build_checker()" || exit 1
 timeout -k 10 900 python tools/long_validation.py 262144 500 100 > $O/validation.txt 2>&1 || { tail -5 $O/validation.txt; exit 1; }
 tail -3 $O/validation.txt
