@@ -234,7 +234,8 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
         rho = rho * (P.mass * P.poly6_norm);                    // sum of (h2 - r2)^3 -> density
         rho = fmaxf(fmaxf(rho, 1.19209290e-07f), 0.1f);
         rho_out[i] = rho;
-        rho2_out[i] = make_float2(P.pressure_k * (rho - P.rest_density), __fdiv_rn(1.0f, rho));
+        rho2_out[i] = make_float2(P.pressure_k * (rho - P.rest_density),
+                                  (P.share_div && rho <= FS_RCP_HI) ? rcp_rn_fast(rho) : __fdiv_rn(1.0f, rho));   // same bits (proven range)
         return;
     }
     rho = fmaxf(rho, 1.19209290e-07f);                          // funcs.wgsl:202
