@@ -42,9 +42,12 @@ WORKLOADS = {
 ALG_BYTES_3D = {"predict_key": 40, "sort": 12, "reorder": 72 + 4, "density": 20, "force": 68}   # 216 B (3D keeps predict+key as its own kernel)
 ALG_TOTAL_3D = 216
 
-# which kernel carries a pass (for the committed rocprofv3 counter summaries)
-PASS_KERNEL = {"force": "k_force<", "density": "k_density", "sort": "k_bitonic_local<true, true>", "reorder": "k_reorder"}
-PASS_KERNEL_3D = {"force": "k3_force", "density": "k3_density", "sort": "k_bitonic_local", "reorder": "k3_reorder"}
+# which kernel carries a pass: EXACT names as rocprofv3 prints them (profiles/counters_latest.json keys), first match wins
+PASS_KERNEL = {"force": ["fsd::k_force<0, false>"], "density": ["fsd::k_density<false>"],
+               "sort": ["fsd::k_bitonic_local<true, true, 4>", "fsd::k_bitonic_local<true, true, 3>"], "reorder": ["fsd::k_reorder<true>"]}
+PASS_KERNEL_3D = {"force": ["fsd::k3_force<0>", "fsd::k3_force"], "density": ["fsd::k3_density<0>", "fsd::k3_density"],
+                  "sort": ["fsd::k_bitonic_local<true, true, 4>", "fsd::k_bitonic_local<true, false, 4>"],
+                  "reorder": ["fsd::k3_reorder"], "predict_key": ["fsd::k3_predict_key"]}
 
 
 def usable_cores():
@@ -163,11 +166,11 @@ def bound_from_evidence(dom, hbm_frac_of_copy, counters, is3d):
     issue slots when they are mostly busy, else latency (waves parked on memory / LDS)."""
     if counters is None:
         return "hbm" if hbm_frac_of_copy >= 0.6 else "unknown (no counter summary committed)", None
-    kern = (PASS_KERNEL_3D if is3d else PASS_KERNEL).get(dom, dom)
     row = None
-    for k, v in counters.get("kernels", {}).items():
-        if kern in k:
-            row = dict(v, kernel=k)
+    for name in (PASS_KERNEL_3D if is3d else PASS_KERNEL).get(dom, [dom]):     # exact kernel names only (no substring match)
+        v = counters.get("kernels", {}).get(name)
+        if v is not None:
+            row = dict(v, kernel=name)
             break
     if row is None:
         return "hbm" if hbm_frac_of_copy >= 0.6 else "unknown (kernel not in the counter summary)", None
@@ -180,6 +183,57 @@ def bound_from_evidence(dom, hbm_frac_of_copy, counters, is3d):
     else:
         b = "latency"
     return b, row
+
+
+def spawn_ranks(n, argv, child=None, env_extra=None, timeout=None):
+    """`python3 bench.py --gpus N` without a launcher: start N rank processes ourselves (what
+    `python -m torch.distributed.run --nproc-per-node N` would do) and relay rank 0's JSON line.
+
+    Runs in a parent that has NOT imported torch or touched HIP, and never replaces itself (no exec): every
+    rank is a fresh child with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set.  Rank 0's stdout
+    is passed through; the other ranks' stdout goes to stderr.  Returns the exit code: 0 only if every rank
+    exited 0; when one rank fails the others are terminated (by PID) instead of waiting in a collective."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                     # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = child if child is not None else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FS_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this pool
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    t_end = None if timeout is None else time.monotonic() + timeout
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: rank {r} exited with {code}; stopping the other ranks\n")
+        timed_out = t_end is not None and time.monotonic() > t_end
+        if (rc != 0 or timed_out) and live:
+            if timed_out and rc == 0:
+                rc = 124
+                sys.stderr.write("bench.py: ranks timed out\n")
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            live.clear()
+        if live:
+            time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -200,9 +254,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python3 bench.py --gpus N`: this process becomes the launcher.  Nothing here imports torch, loads the
+        # HIP library or initialises the GPU; the build (hipcc child processes) happens before any rank exists.
+        if not (args.no_build or under_profiler()):
+            import __graft_entry__ as ge
+            ge._load_build_module().build(verbose=False)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if world != args.gpus and not (world > 1 and args.gpus == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                         "(torch.distributed.run), or run bare `python3 bench.py --gpus N`")
     if world > 1:
         # torch first: its bundled HIP runtime has the same SONAME as /opt/rocm's, so the engine
         # library binds to the one already loaded (one runtime per process).
@@ -242,10 +303,9 @@ def main():
     # roofline: the SAME window once more on a fresh handle, now with a HIP event at every pass boundary
     # (they serialise the kernel boundaries and cost ~1 %, which is why the headline window runs without them)
     ms_profiled, per_pass = run_window(make_sim, tick, args.warmup, args.steps, n, alg_bytes)
-    # the dominant KERNEL: a pass's time x the share its largest kernel has of it (the sort pass is ~16 launches, the
-    # largest ~41 % of it; the force pass is the lean kernel + the general one, profiles/r02_k_kernel_stats.csv)
-    share = {"sort": 0.41, "force": 0.94, "density": 1.0, "reorder": 0.97, "predict_key": 1.0}
-    dom = max(per_pass, key=lambda k: per_pass[k]["ms"] * share.get(k, 1.0))
+    # the dominant pass = the longest event interval of THIS run (force = the lean kernel + the general one; the per-kernel
+    # split of the same command is the committed rocprofv3 summary, profiles/*_kernel_stats.csv)
+    dom = max(per_pass, key=lambda k: per_pass[k]["ms"])
 
     traffic, traffic_src = args.pmc_traffic, "--pmc-traffic argument (separate rocprofv3 --pmc run of this command)"
     if traffic is None:
@@ -339,6 +399,12 @@ def main():
                 wl[name] = {"value": round(m / (t * 1e-3) / 1e6, 2), "ms_per_step": round(t, 4), "particles": m,
                             "passes_ms": {k: v["ms"] for k, v in tab.items()},
                             "step_frac_of_hbm_peak": round(at * m / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                d3 = max(tab, key=lambda k: tab[k]["ms"])       # this workload's own dominant pass, bound from ITS counters
+                b3, c3 = bound_from_evidence(d3, tab[d3]["alg_GBps"] / HBM_COPY_GBS, counters, name.startswith("dam_break_3d"))
+                wl[name]["roofline"] = {"bound": b3, "kernel": d3, "achieved": tab[d3]["alg_GBps"], "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": tab[d3]["frac"], "alg_bytes_per_particle": ab[d3],
+                                        "valu_issue_frac": c3.get("valu_issue_frac") if c3 else None,
+                                        "counter_kernel": c3.get("kernel") if c3 else None, "traffic": None}
             except Exception as e:      # an extra must never take the headline down with it
                 wl[name] = {"error": str(e)}
         out["alt_workloads"] = dict(wl, note="10 warm-up + 100 timed steps each, strict mode, one GPU; 3D has no reference counterpart")
