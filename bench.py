@@ -44,9 +44,10 @@ ALG_TOTAL_3D = 216
 
 # which kernel carries a pass: EXACT names as rocprofv3 prints them (profiles/counters_latest.json keys), first match wins
 PASS_KERNEL = {"force": ["fsd::k_force<0, false>"], "density": ["fsd::k_density<false>"],
-               "sort": ["fsd::k_bitonic_local<true, true, 4>", "fsd::k_bitonic_local<true, true, 3>"], "reorder": ["fsd::k_reorder<true>"]}
+               "sort": ["fsd::k_bitonic_local<true, 1, 4>", "fsd::k_bitonic_local<true, 1, 3>", "fsd::k_bitonic_local<true, true, 4>"],
+               "reorder": ["fsd::k_reorder<true>"]}
 PASS_KERNEL_3D = {"force": ["fsd::k3_force<0>", "fsd::k3_force"], "density": ["fsd::k3_density<0>", "fsd::k3_density"],
-                  "sort": ["fsd::k_bitonic_local<true, true, 4>", "fsd::k_bitonic_local<true, false, 4>"],
+                  "sort": ["fsd::k_bitonic_local<true, 2, 4>", "fsd::k_bitonic_local<true, false, 4>"],
                   "reorder": ["fsd::k3_reorder"], "predict_key": ["fsd::k3_predict_key"]}
 
 

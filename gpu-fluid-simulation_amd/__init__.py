@@ -288,12 +288,12 @@ def dam_break_3d(n):
 class FluidSimulation3D:
     """3D extension (include/fluidsim.h fs3_*); not in the reference."""
 
-    def __init__(self, settings, device=0, initial_offset=(0.0, 0.0, 0.0)):
+    def __init__(self, settings, device=0, initial_offset=(0.0, 0.0, 0.0), math_mode=FS_MATH_IEEE):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.settings = settings
         off = Vec3(*[float(x) for x in initial_offset])
-        _check(self._lib, self._lib.fs3_create(C.byref(settings), int(device), off, C.byref(self._h)))
+        _check(self._lib, self._lib.fs3_create_ex(C.byref(settings), int(device), off, int(math_mode), C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -374,6 +374,7 @@ class SlabSimulation:
                               int(recv_capacity), int(max_cols), 0 if sort_mode is None else 1 + int(sort_mode))
         _check(self._lib, self._lib.fs_slab_create(C.byref(settings), int(device), C.byref(self.cfg), C.byref(self._h)))
         self.capacity = int(capacity)
+        self.device_index = int(device)
         self.message_bytes = int(self._lib.fs_slab_message_bytes(self._h))
 
     def close(self):
@@ -435,6 +436,10 @@ class SlabSimulation:
         v = C.c_float()
         _check(self._lib, self._lib.fs_slab_max_speed(self._h, C.byref(v)))
         return float(v.value)
+
+    def rebalance_stats(self, stats_dev_ptr, hist_dev_ptr, grid_w_global):
+        """Enqueue the re-balancing inputs into two DEVICE buffers (4 x u32 stats, grid_w x u32 histogram); no read-back."""
+        _check(self._lib, self._lib.fs_slab_rebalance_stats(self._h, stats_dev_ptr, hist_dev_ptr, int(grid_w_global)))
 
     def profile(self, enable=True):
         _check(self._lib, self._lib.fs_profile_enable(self._h, 1 if enable else 0))

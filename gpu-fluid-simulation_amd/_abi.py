@@ -228,7 +228,9 @@ PROTOTYPES = {
     "fs_slab_download": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     "fs_slab_column_histogram": (C.c_int, [_P, _P, C.c_size_t]),
     "fs_slab_max_speed": (C.c_int, [_P, _P]),
+    "fs_slab_rebalance_stats": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "fs3_create": (C.c_int, [C.POINTER(Settings3), C.c_int, Vec3, C.POINTER(_P)]),
+    "fs3_create_ex": (C.c_int, [C.POINTER(Settings3), C.c_int, Vec3, C.c_int, C.POINTER(_P)]),
     "fs3_destroy": (None, [_P]),
     "fs3_step": (C.c_int, [_P, C.POINTER(TickSettings3)]),
     "fs3_sync": (C.c_int, [_P]),

@@ -141,8 +141,10 @@ struct fs_sim {
     bool slab = false;
     fs_slab_config slab_cfg{};
     uint32_t slab_main = 0;         // capacity - 2 * recv_capacity
-    DevArray<unsigned char> owned, flags;
-    DevArray<uint2> blockcnt, blockoff;
+    DevArray<unsigned char> owned;
+    DevArray<uint2> blockcnt;           // per 256-slot block: records for the left / right message (k_slab_pack)
+    DevArray<uint32_t> stage;           // ... and the slots themselves, 2 x 256 entries per block
+    DevArray<fsd::u64> msg_state;       // k_slab_msg's look-back words
     DevArray<uint32_t> slab_counters;   // [0] n_live, [2] lost, [3] overflow, [4] far_halo
     DevArray<uint32_t> hist;
     bool slab_packed = false;
@@ -163,7 +165,7 @@ struct fs_sim {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release(); rho2.release();
         key.release(); safe.release(); fdefer.release(); fwork.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
-        owned.release(); flags.release(); blockcnt.release(); blockoff.release(); slab_counters.release();
+        owned.release(); blockcnt.release(); stage.release(); msg_state.release(); slab_counters.release();
         hist.release();
         for (auto& e : ev) (void)hipEventDestroy(e);
         ev.clear();
@@ -391,7 +393,7 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     const bool counting = s->opts.sort_mode == FS_SORT_COUNTING;
     if (prof) FS_HIP(hipEventRecord(ev[1], st));
     if (counting) {
-        fsd::launch_counting_sort(st, P, s->pos.p, s->vel.p, s->pairs.p, s->cs.p, s->csort.p, s->counter.p);
+        fsd::launch_counting_sort(st, P, s->pos.p, s->vel.p, s->cs.p, s->csort.p, s->counter.p, s->safe.p, s->tick);
     } else {
         fsd::SortPlan plan;
         if (!s->sortp.plan(s->n, &plan)) return fail(FS_ERR_DEVICE, "sort: the stand-by kernel's grid barrier timed out");
@@ -399,8 +401,12 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     }
     if (prof) FS_HIP(hipEventRecord(ev[2], st));
     s->key_in_pairs = true;        // the 4 B / particle of a second copy of the keys stay unwritten
-    fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, (uint32_t*)nullptr, s->cs.p,
-                        s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, s->fdefer.p, s->counter.p + 4, counting);
+    if (counting)      // rank fix-up of the counting sort fused with the reorder pass (kernels_csort.hip)
+        fsd::launch_counting_reorder(st, P, s->csort.p, s->pairs.p, s->cs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
+                                     (uint32_t*)nullptr, s->start_ref.p, s->safe.p, s->fdefer.p, s->counter.p + 4);
+    else
+        fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, (uint32_t*)nullptr, s->cs.p,
+                            s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, s->fdefer.p, s->counter.p + 4);
     if (prof) FS_HIP(hipEventRecord(ev[3], st));
     // strict / ulp modes: rho2.x IS the density; the separate 4-byte copy is only written in tolerance mode (rho2 = {P, 1/rho})
     s->rho_in_rho2 = P.fast_math != 2;
@@ -497,7 +503,10 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     FS_TRY(s->tex.alloc((size_t)settings->texture_size.x * settings->texture_size.y));
     FS_TRY(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
     FS_TRY(s->counter.alloc(8));
-    if (opts->sort_mode == FS_SORT_COUNTING) FS_TRY(s->csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
+    if (opts->sort_mode == FS_SORT_COUNTING) {
+        FS_TRY(s->csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
+        FS_TRY(hipMemsetAsync(s->csort.p, 0, s->csort.n * sizeof(uint32_t), s->stream));   // histogram / tickets: zero between steps
+    }
     FS_TRY(hipEventCreate(&s->t0));
     FS_TRY(hipEventCreate(&s->t1));
     FS_TRY(s->sortp.init(8));
@@ -928,6 +937,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     if (cfg->capacity <= 2 * cfg->recv_capacity || cfg->recv_capacity == 0)
         return fail(FS_ERR_INVALID, "capacity must exceed 2*recv_capacity");
     if (cfg->capacity > (1u << 28)) return fail(FS_ERR_INVALID, "capacity > 2^28");
+    if (cfg->recv_capacity >= (1u << 20) - 2u) return fail(FS_ERR_INVALID, "recv_capacity >= 2^20 - 2 (message counters are 20-bit fields)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(FS_ERR_DEVICE, "no HIP device: the engine has no CPU fallback");
@@ -977,12 +987,16 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc((cap + 63) / 64 + 1)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
-    FS_TRY(s->owned.alloc(cap)); FS_TRY(s->flags.alloc(cap));
+    FS_TRY(s->owned.alloc(cap));
     const size_t nblocks = (cap + 255) / 256;
-    FS_TRY(s->blockcnt.alloc(nblocks)); FS_TRY(s->blockoff.alloc(nblocks));
+    FS_TRY(s->blockcnt.alloc(nblocks + 1));
+    FS_TRY(s->stage.alloc(fsd::slab_stage_words((uint32_t)cap)));
+    FS_TRY(s->msg_state.alloc(fsd::slab_msg_groups((uint32_t)cap) + 1));
+    FS_TRY(hipMemsetAsync(s->msg_state.p, 0, s->msg_state.n * sizeof(fsd::u64), s->stream));
     FS_TRY(s->slab_counters.alloc(8));
     FS_TRY(s->hist.alloc(gw));
     FS_TRY(s->csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
+    FS_TRY(hipMemsetAsync(s->csort.p, 0, s->csort.n * sizeof(uint32_t), s->stream));       // histogram / tickets: zero between steps
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1)); FS_TRY(s->start_ref.alloc(s->ncell));
     FS_TRY(s->tex.alloc((size_t)settings->texture_size.x * settings->texture_size.y));
     FS_TRY(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
@@ -995,7 +1009,6 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(hipMemsetAsync(s->counter.p, 0, 8 * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->slab_counters.p, 0, 8 * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->owned.p, 0, cap, s->stream));
-    FS_TRY(hipMemsetAsync(s->flags.p, 0, cap, s->stream));
     FS_TRY(hipMemsetAsync(s->rho.p, 0, cap * sizeof(float), s->stream));
     FS_TRY(hipMemsetAsync(s->pos.p, 0, cap * sizeof(float2), s->stream));
     FS_TRY(hipMemsetAsync(s->vel.p, 0, cap * sizeof(float2), s->stream));
@@ -1056,10 +1069,13 @@ fs_status fs_slab_pack(fs_sim* s, const fs_tick_settings* t, void* send_left, vo
         if (s->prof_pending == fs_sim::PROF_RING) { r = drain_profile(s); if (r != FS_OK) return r; }
         FS_HIP(hipEventRecord(s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)], s->stream));
     }
+    const bool counting = s->opts.sort_mode == FS_SORT_COUNTING;
     fsd::launch_slab_pack(s->stream, P, s->slab_main, s->slab_cfg.recv_capacity, (int)s->slab_cfg.has_left,
-                          (int)s->slab_cfg.has_right, s->pos.p, s->vel.p, s->owned.p, s->pairs.p, s->flags.p,
-                          s->blockcnt.p, s->blockoff.p, s->slab_cfg.has_left ? send_left : nullptr,
-                          s->slab_cfg.has_right ? send_right : nullptr, s->slab_counters.p, s->counter.p);
+                          (int)s->slab_cfg.has_right, s->pos.p, s->vel.p, s->owned.p,
+                          counting ? fsd::counting_sort_kt(s->csort.p, s->capacity, s->ncell) : s->pairs.p,
+                          fsd::counting_sort_hist(s->csort.p), s->blockcnt.p, s->stage.p, s->msg_state.p, s->tick,
+                          s->slab_cfg.has_left ? send_left : nullptr,
+                          s->slab_cfg.has_right ? send_right : nullptr, s->slab_counters.p, s->counter.p, s->safe.p, counting);
     FS_HIP(hipGetLastError());
     s->slab_packed = true;
     s->state_lo = s->slab_cfg.own_lo; s->state_hi = s->slab_cfg.own_hi;
@@ -1075,23 +1091,28 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     const fsd::StepParams P = make_params(*s);
     hipStream_t st = s->stream;
     hipEvent_t* ev = s->slab_prof ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
-    fsd::launch_slab_unpack(st, P, s->slab_main, s->slab_cfg.recv_capacity, s->slab_cfg.has_left ? recv_left : nullptr,
-                            s->slab_cfg.has_right ? recv_right : nullptr, s->pos.p, s->vel.p, s->pairs.p,
-                            s->slab_counters.p);
-    if (ev) FS_HIP(hipEventRecord(ev[1], st));
     const bool counting = s->opts.sort_mode == FS_SORT_COUNTING;
+    fsd::launch_slab_unpack(st, P, s->slab_main, s->slab_cfg.recv_capacity, s->slab_cfg.has_left ? recv_left : nullptr,
+                            s->slab_cfg.has_right ? recv_right : nullptr, s->pos.p, s->vel.p,
+                            counting ? fsd::counting_sort_kt(s->csort.p, s->capacity, s->ncell) : s->pairs.p,
+                            fsd::counting_sort_hist(s->csort.p), s->slab_counters.p, counting);
+    if (ev) FS_HIP(hipEventRecord(ev[1], st));
     if (counting) {
-        fsd::launch_counting_sort_pairs(st, s->capacity, P.ncell, s->pairs.p, s->cs.p, s->csort.p, s->counter.p,
-                                        s->slab_counters.p);
+        fsd::launch_counting_sort_pairs(st, s->capacity, P.ncell, s->ncell, s->cs.p, s->csort.p, s->slab_counters.p, s->tick);
     } else {
         fsd::SortPlan per_stage;               // ghosts arrive at the end of the array every step: they travel far, no shifted merge
         per_stage.fuse_stage = 0;
         fsd::launch_bitonic_sort(st, s->pairs.p, s->capacity, s->sort_dirty.p, nullptr, nullptr, nullptr, nullptr, &per_stage);
     }
     if (ev) FS_HIP(hipEventRecord(ev[2], st));
-    fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
-                             s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,
-                             s->slab_counters.p, s->safe.p, s->fdefer.p, s->counter.p + 4, counting);
+    if (counting)
+        fsd::launch_counting_reorder_slab(st, P, s->capacity, s->ncell, s->csort.p, s->pairs.p, s->cs.p, s->pos.p, s->vel.p, s->pos_s.p,
+                                          s->vel_s.p, s->pred.p, s->key.p, s->owned.p, s->start_ref.p, s->safe.p, s->fdefer.p,
+                                          s->counter.p + 4);
+    else
+        fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
+                                 s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,
+                                 s->slab_counters.p, s->safe.p, s->fdefer.p, s->counter.p + 4);
     if (ev) FS_HIP(hipEventRecord(ev[3], st));
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
     if (ev) FS_HIP(hipEventRecord(ev[4], st));
@@ -1124,6 +1145,25 @@ fs_status fs_slab_max_speed(fs_sim* s, float* out) {
     FS_HIP(hipMemcpyAsync(&bits, s->slab_counters.p + 5, sizeof bits, hipMemcpyDeviceToHost, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));
     std::memcpy(out, &bits, sizeof bits);
+    return FS_OK;
+}
+
+/* Re-balancing inputs left ON THE DEVICE, on the simulation's stream, nothing read back: `hist_dev[grid_w_global]` =
+ * particles per global column (zero outside the owned window), `stats_dev[4]` = {lost, overflow, far_halo, bits of the
+ * largest owned |velocity|} — all four reduce with MAX as u32 (non-negative floats order like their bits).  The caller
+ * all-reduces both buffers (fs_comm_allreduce, or any collective ordered after this stream) and reads them once. */
+fs_status fs_slab_rebalance_stats(fs_sim* s, uint32_t* stats_dev, uint32_t* hist_dev, size_t grid_w_global) {
+    if (!s || !s->slab || !stats_dev || !hist_dev || grid_w_global < s->grid_w) return fail(FS_ERR_INVALID, "bad argument");
+    if (s->slab_packed) return fail(FS_ERR_INVALID, "fs_slab_rebalance_stats between pack and step");
+    FS_HIP(hipSetDevice(s->device));
+    const fsd::StepParams P = make_params_of_state(*s);
+    FS_HIP(hipMemsetAsync(hist_dev, 0, grid_w_global * sizeof(uint32_t), s->stream));
+    fsd::launch_slab_colhist(s->stream, P, s->cs.p, hist_dev);
+    FS_HIP(hipMemsetAsync(s->slab_counters.p + 5, 0, sizeof(uint32_t), s->stream));
+    fsd::launch_slab_maxspeed(s->stream, s->slab_counters.p, s->vel.p, s->owned.p, s->slab_counters.p + 5);
+    // counters [2] lost, [3] overflow, [4] far_halo, [5] max-speed bits are adjacent
+    FS_HIP(hipMemcpyAsync(stats_dev, s->slab_counters.p + 2, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    FS_HIP(hipGetLastError());
     return FS_OK;
 }
 

@@ -52,17 +52,24 @@ size_t gap_entry_size();
 void launch_fill_gaps(hipStream_t st, uint32_t* cs, const void* work, const uint32_t* counter, uint32_t work_cap);
 
 // ---- slab (multi-GPU) mode, kernels_slab.hip -------------------------------------------------
+// `out`: the counting sort's (key, ticket) words (counting_sort_kt) or, in bitonic mode, the pairs; `blockcnt`: one uint2 per
+// 256-slot block; `stage`: slab_stage_words(capacity) words; `state`: one u64 per slab_msg_groups(capacity) (look-back);
+// `epoch`: a number unique to this launch among the handle's launches (the tick).  counters[6] is the look-back's ticket.
 void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, int has_left,
-                      int has_right, const float2* pos, const float2* vel, const unsigned char* owned, u64* pairs,
-                      unsigned char* flags, void* blockcnt, void* blockoff, void* msg_left, void* msg_right,
-                      uint32_t* counters, uint32_t* gap_counter);
+                      int has_right, const float2* pos, const float2* vel, const unsigned char* owned, u64* out,
+                      uint32_t* hist, void* blockcnt, uint32_t* stage, void* state, uint32_t epoch,
+                      void* msg_left, void* msg_right, uint32_t* counters, uint32_t* gap_counter, unsigned long long* safe,
+                      bool counting);
+size_t slab_stage_words(uint32_t cap);
+size_t slab_msg_groups(uint32_t cap);
 void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, const void* msg_left,
-                        const void* msg_right, float2* pos, float2* vel, u64* pairs, uint32_t* counters);
+                        const void* msg_right, float2* pos, float2* vel, u64* out, uint32_t* hist, uint32_t* counters,
+                        bool counting);
 void launch_slab_reorder(hipStream_t st, const StepParams& P, uint32_t cap, const u64* pairs, const float2* pos_in,
                          const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s, uint32_t* key_s,
                          unsigned char* owned, uint32_t* cs, uint32_t* start_ref, void* work, uint32_t* counter,
                          uint32_t work_cap, uint32_t* n_live_out, unsigned long long* safe, uint32_t* force_defer,
-                         uint32_t* force_work_count, bool cs_ready = false);
+                         uint32_t* force_work_count);
 void launch_slab_export(hipStream_t st, const StepParams& P, uint32_t cap, const float2* pos, const float2* pred,
                         const float2* vel, const float* rho, const uint32_t* key, void* out);
 void launch_slab_import(hipStream_t st, const StepParams& P, uint32_t n, uint32_t cap, const void* in, float2* pos,
@@ -84,20 +91,38 @@ struct SortPlan {
     uint32_t* feedback = nullptr;  // host-visible words the certificate reports to (stage, verdict, fit class, seq), or none
     uint32_t seq = 0;
 };
+// keygen3d != nullptr (3D engine): the same fusion with float4 pos / vel and the 3D cell key.
+struct KeyGen3 { float dt, h, bx, by, bz; uint32_t gw, gh; };
 int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty, const StepParams* keygen = nullptr,
                         const float2* pos = nullptr, const float2* vel = nullptr, uint32_t* gap_counter = nullptr,
-                        const SortPlan* plan = nullptr);
+                        const SortPlan* plan = nullptr, const KeyGen3* keygen3d = nullptr, const float4* pos4 = nullptr,
+                        const float4* vel4 = nullptr);
 // dirty[sort_plan_word(n) ..]: [0] verdict of the last certificate, [1] / [2] shifted-merge / per-stage plan counters,
 // [3] fallback barrier, [4] fallback barrier time-outs, [5] fit class
 uint32_t sort_plan_word(uint32_t n);
 #define FS_SORT_NO_PLAN 255u
 uint32_t sort_tile_count(uint32_t n);
 
-// FS_SORT_COUNTING (kernels_csort.hip): fills `pairs` (stable order) and the dense table `cs`.
-size_t counting_sort_scratch_words(uint32_t n, uint32_t ncell);
-void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, u64* pairs, uint32_t* cs, uint32_t* scratch,
-                                uint32_t* gap_counter, uint32_t* n_live_out);
-void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, u64* pairs,
-                          uint32_t* cs, uint32_t* scratch, uint32_t* gap_counter);
+// FS_SORT_COUNTING (kernels_csort.hip).  The scratch must be all-zero when the handle is created (histogram, tickets);
+// every step leaves it that way.  `epoch`: a number unique to the launch among the handle's launches.
+//   single domain: launch_counting_sort (hist -> scan -> scatter: fills `cs`) + launch_counting_reorder (rank fix-up fused
+//   with the whole reorder pass: fills `pairs`, pos_s / vel_s / pred_s, start_ref, safe bits);
+//   slabs: k_slab_pack / k_slab_unpack fill the histogram, then launch_counting_sort_pairs (scan -> scatter; live count)
+//   + launch_counting_reorder_slab.
+size_t counting_sort_scratch_words(uint32_t n, uint32_t ncell_max);
+u64* counting_sort_kt(uint32_t* scratch, uint32_t n, uint32_t ncell_alloc);
+uint32_t* counting_sort_hist(uint32_t* scratch);
+void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, uint32_t* cs,
+                          uint32_t* scratch, uint32_t* gap_counter, unsigned long long* safe, uint32_t epoch);
+void launch_counting_reorder(hipStream_t st, const StepParams& P, uint32_t* scratch, u64* pairs, const uint32_t* cs,
+                             const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s,
+                             uint32_t* key_s, uint32_t* start_ref, unsigned long long* safe, uint32_t* force_defer,
+                             uint32_t* force_work_count);
+void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, uint32_t ncell_alloc, uint32_t* cs, uint32_t* scratch,
+                                uint32_t* n_live_out, uint32_t epoch);
+void launch_counting_reorder_slab(hipStream_t st, const StepParams& P, uint32_t cap, uint32_t ncell_alloc, uint32_t* scratch, u64* pairs,
+                                  const uint32_t* cs, const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s,
+                                  float2* pred_s, uint32_t* key_s, unsigned char* owned, uint32_t* start_ref,
+                                  unsigned long long* safe, uint32_t* force_defer, uint32_t* force_work_count);
 
 }  // namespace fsd

@@ -3,14 +3,11 @@
 // inside a cell) instead of the bitonic network's tie order, so floats agree with the
 // reference path only to summation-order tolerance; keys and cell starts are identical.
 // Deterministic (no dependence on atomic arrival order):
-//   k_cs_hist      key per particle, per-cell histogram (atomics only count)
-//   k_cs_scan_*    exclusive scan of the histogram = dense cell-start table `cs`
-//   k_cs_scatter   slot = cs[key] + arrival ticket          (order inside a cell arbitrary)
-//   k_cs_fixup     each slot ranks its source index inside its cell segment and writes the
-//                  (key, src) pair at cs[key] + rank          (order inside a cell = by source)
-// The pairs then feed the same k_reorder / density / force chain as the bitonic mode.
+// (atomics only hand out tickets; the final order inside a cell is by source index) — kernels below.
+// The pairs then feed the same density / force chain as the bitonic mode.
 #include "fs_device.h"
 #include "fs_kernels.h"
+#include "fs_scan.h"
 
 namespace fsd {
 
@@ -18,210 +15,230 @@ namespace fsd {
 #define CS_ITEMS 16
 #define CS_TILE (CS_BLOCK * CS_ITEMS)
 
-// Consecutive particles mostly share a cell (the input is the previous step's cell order), so a
-// wave would hit the same counter several times.  Runs of equal keys in adjacent lanes are
-// combined: the run's first lane issues ONE atomic for the whole run.
-struct WaveRun { uint32_t head_lane, offset, length; bool is_head; };
-__device__ __forceinline__ WaveRun wave_run(uint32_t key, bool active) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t prev = __shfl_up(key, 1);
-    const bool prev_active = __shfl_up(active ? 1 : 0, 1) != 0;
-    const bool head = active && (lane == 0 || !prev_active || prev != key);
-    const unsigned long long heads = __ballot(head), act = __ballot(active);
-    WaveRun r;
-    r.is_head = head;
-    const unsigned long long upto = heads & (~0ull >> (63u - lane));            // heads at lanes <= mine
-    r.head_lane = upto ? 63u - (uint32_t)__clzll(upto) : lane;
-    r.offset = lane - r.head_lane;
-    const unsigned long long after = (lane == 63u) ? 0ull : ((heads | ~act) & (~0ull << (lane + 1u)));
-    // run ends at the next head or the first inactive lane after me
-    const uint32_t end = after ? (uint32_t)__ffsll((long long)after) - 1u : 64u;
-    r.length = end - r.head_lane;
-    return r;
-}
+// ---- pipeline (round 3): 4 launches, no memset, atomics only in the histogram -------------------------------
+//   k_cs_hist        predict + key per particle; per-cell histogram with wave-aggregated atomics.  The value the
+//                    atomic returns is the particle's ARRIVAL TICKET inside its cell: stored beside the key
+//                    (kt[i] = key << 32 | ticket), so the scatter needs no second atomic pass and no cursor array.
+//   k_scan_lookback  exclusive scan of the histogram = dense cell-start table `cs`, ONE launch (decoupled
+//                    look-back, fs_scan.h); zeroes the histogram behind itself (invariant: all-zero between steps).
+//   k_cs_scatter     slot_src[cs[key] + ticket] = i                  (order inside a cell = arrival order)
+//   k_cs_fixreorder  each slot ranks its source index inside its cell segment -> final position d = cs[key] + rank
+//                    (order inside a cell = by source index: deterministic), and does the WHOLE reorder pass for d
+//                    right there: payload gather, predicted position, start_indices, safe-operand bit, (key, src) pair.
+// The "safe operand" words (fs_device.h) are written by ballot in k_reorder; here a thread does not own a whole
+// wave of sorted positions, so the words are preset to all-ones by k_cs_hist and unsafe particles clear their bit.
 
 __global__ __launch_bounds__(CS_BLOCK) void k_cs_hist(StepParams P, const float2* __restrict__ pos,
-                                                      const float2* __restrict__ vel, uint32_t* __restrict__ key_out,
-                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ gap_counter) {
+                                                      const float2* __restrict__ vel, u64* __restrict__ kt,
+                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ gap_counter,
+                                                      unsigned long long* __restrict__ safe) {
     const uint32_t i = blockIdx.x * CS_BLOCK + threadIdx.x;
     if (i == 0) *gap_counter = 0;
+    if (i < (P.n + 63u) / 64u) safe[i] = ~0ull;
     const bool active = i < P.n;
     uint32_t key = 0;
-    if (active) { key = cell_of_point(P, predict_pos(P, pos[i], vel[i])); key_out[i] = key; }
+    if (active) key = cell_of_point(P, predict_pos(P, pos[i], vel[i]));
     const uint32_t k = key < P.ncell ? key : P.ncell - 1u;
     const WaveRun r = wave_run(k, active);
-    if (r.is_head) atomicAdd(&hist[k], r.length);
+    uint32_t base = 0;
+    if (r.is_head) base = atomicAdd(&hist[k], r.length);            // one ticket block per run
+    base = __shfl(base, r.head_lane);
+    if (active) kt[i] = ((u64)key << 32) | (u64)(base + r.offset);
 }
 
-__global__ __launch_bounds__(CS_BLOCK) void k_cs_scan_reduce(const uint32_t* __restrict__ in, uint32_t count,
-                                                             uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t s[CS_BLOCK / 64];
-    const uint32_t base = blockIdx.x * CS_TILE;
-    uint32_t sum = 0;
+// Exclusive scan of in[0, count) -> out, one launch.  Tile = SCAN_TILE items per workgroup (1024 threads x 16: the
+// look-back's prefix frontier advances ~128 tiles per global-memory round trip, so tiles must be FEW — 641 for the
+// 10.5 M cells of the 16 M scene — for the chain to hide under the streaming), thread t owns 16 consecutive items
+// (four 16-byte loads).  `in` is zeroed behind the read; `in`, `out` 16-byte aligned.  total_out (may be null)
+// receives the grand total.
+#define SCAN_BLOCK 1024
+#define SCAN_ITEMS 16
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_lookback(uint32_t* __restrict__ in, uint32_t count,
+                                                              uint32_t* __restrict__ out, u64* __restrict__ state,
+                                                              uint32_t* __restrict__ ticket, uint32_t epoch,
+                                                              uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
+    __shared__ uint32_t s_bid, s_excl;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid, nblocks = gridDim.x;
+    if (bid == nblocks - 1u && threadIdx.x == 0) *ticket = 0u;      // every ticket of this launch has been handed out
+    const uint32_t base = bid * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], sum = 0;
+    if (base + SCAN_ITEMS <= count) {
 #pragma unroll
-    for (uint32_t k = 0; k < CS_ITEMS; ++k) {
-        const uint32_t j = base + k * CS_BLOCK + threadIdx.x;
-        if (j < count) sum += in[j];
+        for (uint32_t k = 0; k < SCAN_ITEMS; k += 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(in + base + k);
+            v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN_ITEMS; k += 4) *reinterpret_cast<uint4*>(in + base + k) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN_ITEMS; ++k) v[k] = (base + k < count) ? in[base + k] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN_ITEMS; ++k) if (base + k < count) in[base + k] = 0u;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if ((threadIdx.x & 63u) == 0) s[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < CS_BLOCK / 64; ++w) t += s[w]; block_sums[blockIdx.x] = t; }
-}
-
-__global__ __launch_bounds__(CS_BLOCK) void k_cs_scan_sums(uint32_t* __restrict__ block_sums, uint32_t nblocks) {
-    __shared__ uint32_t s[CS_BLOCK];
-    const uint32_t chunk = (nblocks + CS_BLOCK - 1) / CS_BLOCK, b0 = threadIdx.x * chunk;
-    uint32_t acc = 0;
-    for (uint32_t b = b0; b < b0 + chunk && b < nblocks; ++b) acc += block_sums[b];
-    s[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < CS_BLOCK; ++t) { const uint32_t v = s[t]; s[t] = run; run += v; } }
-    __syncthreads();
-    uint32_t run = s[threadIdx.x];
-    for (uint32_t b = b0; b < b0 + chunk && b < nblocks; ++b) { const uint32_t v = block_sums[b]; block_sums[b] = run; run += v; }
-}
-
-// Exclusive scan of one tile with its block offset; thread t owns CS_ITEMS consecutive items.
-__global__ __launch_bounds__(CS_BLOCK) void k_cs_scan_apply(const uint32_t* __restrict__ in, uint32_t count,
-                                                            const uint32_t* __restrict__ block_offs,
-                                                            uint32_t* __restrict__ out) {
-    __shared__ uint32_t s[CS_BLOCK];
-    const uint32_t base = blockIdx.x * CS_TILE + threadIdx.x * CS_ITEMS;
-    uint32_t v[CS_ITEMS], sum = 0;
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k) sum += v[k];
+    // inclusive scan of the thread sums: wave scan + the 16 wave totals
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t inc = sum;
 #pragma unroll
-    for (uint32_t k = 0; k < CS_ITEMS; ++k) { v[k] = (base + k < count) ? in[base + k] : 0u; sum += v[k]; }
-    s[threadIdx.x] = sum;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
+    if (lane == 63u) s_wave[w] = inc;
     __syncthreads();
-    for (uint32_t o = 1; o < CS_BLOCK; o <<= 1) {          // Hillis-Steele inclusive scan of the 256 sums
-        const uint32_t add = threadIdx.x >= o ? s[threadIdx.x - o] : 0u;
-        __syncthreads();
-        s[threadIdx.x] += add;
-        __syncthreads();
+    uint32_t wave_off = 0, tile_total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_BLOCK / 64; ++k) { const uint32_t t = s_wave[k]; if (k < w) wave_off += t; tile_total += t; }
+    const u64 tag = (u64)(epoch & 0x3FFFFFFFu);
+    if (w == 0) {
+        if (bid == 0) {
+            if (lane == 0) { lb_store(state, (LB_FLAG_PREFIX << 62) | (tag << 32) | (u64)tile_total); s_excl = 0u; }
+        } else {
+            if (lane == 0) lb_store(state + bid, (LB_FLAG_AGG << 62) | (tag << 32) | (u64)tile_total);
+            const u64 ex = lookback_exclusive<32>(state, bid, tag, [](u64 a, u64 b) { return (a + b) & 0xFFFFFFFFull; });
+            if (lane == 0) {
+                lb_store(state + bid, (LB_FLAG_PREFIX << 62) | (tag << 32) | ((ex + tile_total) & 0xFFFFFFFFull));
+                s_excl = (uint32_t)ex;
+            }
+        }
     }
-    uint32_t run = block_offs[blockIdx.x] + s[threadIdx.x] - sum;
+    __syncthreads();
+    uint32_t run = s_excl + wave_off + inc - sum;
+    if (base + SCAN_ITEMS <= count) {
 #pragma unroll
-    for (uint32_t k = 0; k < CS_ITEMS; ++k) { if (base + k < count) out[base + k] = run; run += v[k]; }
+        for (uint32_t k = 0; k < SCAN_ITEMS; k += 4) {
+            uint4 q;
+            q.x = run; run += v[k]; q.y = run; run += v[k + 1]; q.z = run; run += v[k + 2]; q.w = run; run += v[k + 3];
+            *reinterpret_cast<uint4*>(out + base + k) = q;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN_ITEMS; ++k) { if (base + k < count) out[base + k] = run; run += v[k]; }
+    }
+    if (total_out && base < count && base + SCAN_ITEMS >= count) *total_out = run;   // the thread that owns item count - 1
 }
 
-__global__ __launch_bounds__(CS_BLOCK) void k_cs_scatter(uint32_t n, uint32_t ncell, const uint32_t* __restrict__ key,
-                                                         const uint32_t* __restrict__ cs, uint32_t* __restrict__ cursor,
-                                                         uint32_t* __restrict__ slot_src) {
+__global__ __launch_bounds__(CS_BLOCK) void k_cs_scatter(uint32_t n, uint32_t ncell, const u64* __restrict__ kt,
+                                                         const uint32_t* __restrict__ cs, uint32_t* __restrict__ slot_src) {
     const uint32_t i = blockIdx.x * CS_BLOCK + threadIdx.x;
-    const bool active = i < n;
-    const uint32_t kk = active ? key[i] : 0u;
+    if (i >= n) return;
+    const u64 e = kt[i];
+    const uint32_t kk = (uint32_t)(e >> 32);
+    if (kk == FS_DEAD_KEY) return;                                  // slab mode: an empty slot
     const uint32_t k = kk < ncell ? kk : ncell - 1u;
-    const WaveRun r = wave_run(k, active);
-    uint32_t base = 0;
-    if (r.is_head) base = cs[k] + atomicAdd(&cursor[k], r.length);    // one ticket block per run
-    base = __shfl(base, r.head_lane);
-    if (active) slot_src[base + r.offset] = i;
+    slot_src[cs[k] + (uint32_t)e] = i;
 }
 
-__global__ __launch_bounds__(CS_BLOCK) void k_cs_fixup(uint32_t n, uint32_t ncell, const uint32_t* __restrict__ key,
-                                                       const uint32_t* __restrict__ cs,
-                                                       const uint32_t* __restrict__ slot_src, u64* __restrict__ pairs) {
-    const uint32_t p = blockIdx.x * CS_BLOCK + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t src = slot_src[p];
-    const uint32_t kk = key[src];
-    const uint32_t k = kk < ncell ? kk : ncell - 1u;
-    const uint32_t lo = cs[k], hi = cs[k + 1u];
-    uint32_t rank = 0;
-    for (uint32_t q = lo; q < hi; ++q) rank += slot_src[q] < src ? 1u : 0u;
-    pairs[lo + rank] = ((u64)kk << 32) | (u64)src;
-}
-
-// ---- slab mode: keys come from the (key<<32 | slot) pairs, DEAD slots are skipped -------------
-__global__ __launch_bounds__(CS_BLOCK) void k_cs_hist_pairs(uint32_t cap, uint32_t ncell, const u64* __restrict__ pairs,
-                                                            uint32_t* __restrict__ key_out, uint32_t* __restrict__ hist,
-                                                            uint32_t* __restrict__ gap_counter) {
-    const uint32_t i = blockIdx.x * CS_BLOCK + threadIdx.x;
-    if (i == 0) *gap_counter = 0;
-    uint32_t key = FS_DEAD_KEY;
-    if (i < cap) { key = (uint32_t)(pairs[i] >> 32); key_out[i] = key; }
-    const bool active = key != FS_DEAD_KEY;
-    const uint32_t k = key < ncell ? key : ncell - 1u;
-    const WaveRun r = wave_run(k, active);
-    if (r.is_head) atomicAdd(&hist[k], r.length);
-}
-
-__global__ __launch_bounds__(CS_BLOCK) void k_cs_scatter_live(uint32_t cap, uint32_t ncell, const uint32_t* __restrict__ key,
-                                                              const uint32_t* __restrict__ cs, uint32_t* __restrict__ cursor,
-                                                              uint32_t* __restrict__ slot_src, uint32_t* __restrict__ n_live_out) {
-    const uint32_t i = blockIdx.x * CS_BLOCK + threadIdx.x;
-    if (i == 0) *n_live_out = cs[ncell];                 // total of the histogram = live particles
-    const uint32_t kk = i < cap ? key[i] : FS_DEAD_KEY;
-    const bool active = kk != FS_DEAD_KEY;
-    const uint32_t k = kk < ncell ? kk : ncell - 1u;
-    const WaveRun r = wave_run(k, active);
-    uint32_t base = 0;
-    if (r.is_head) base = cs[k] + atomicAdd(&cursor[k], r.length);
-    base = __shfl(base, r.head_lane);
-    if (active) slot_src[base + r.offset] = i;
-}
-
-__global__ __launch_bounds__(CS_BLOCK) void k_cs_fixup_live(uint32_t cap, uint32_t ncell, const uint32_t* __restrict__ key,
+// Fused rank fix-up + reorder pass (k_reorder<false> / k_slab_reorder<false> of round 2).  SLAB: `n` = slot capacity,
+// the live count is cs[ncell]; slots past it become DEAD pairs.
+template <bool SLAB>
+__global__ __launch_bounds__(CS_BLOCK) void k_cs_fixreorder(StepParams P, uint32_t n, const u64* __restrict__ kt,
                                                             const uint32_t* __restrict__ cs,
-                                                            const uint32_t* __restrict__ slot_src, u64* __restrict__ pairs) {
+                                                            const uint32_t* __restrict__ slot_src, u64* __restrict__ pairs,
+                                                            const float2* __restrict__ pos_in, const float2* __restrict__ vel_in,
+                                                            float2* __restrict__ pos_s, float2* __restrict__ vel_s,
+                                                            float2* __restrict__ pred_s, uint32_t* __restrict__ key_s,
+                                                            unsigned char* __restrict__ owned, uint32_t* __restrict__ start_ref,
+                                                            unsigned long long* __restrict__ safe, uint32_t* __restrict__ force_defer,
+                                                            uint32_t* __restrict__ force_work_count) {
     const uint32_t p = blockIdx.x * CS_BLOCK + threadIdx.x;
-    if (p >= cap) return;
-    const uint32_t n_live = cs[ncell];
-    if (p >= n_live) { pairs[p] = ((u64)FS_DEAD_KEY << 32) | (u64)p; return; }
+    if (threadIdx.x == 0) {                      // the force pass's worklists of this step (same block size and count)
+        force_defer[2u * blockIdx.x] = 0u;
+        force_defer[2u * blockIdx.x + 1u] = 0u;
+        if (blockIdx.x == 0) { force_work_count[0] = 0u; force_work_count[1] = 0u; }
+    }
+    if (p >= n) return;
+    if (SLAB) {
+        const uint32_t n_live = cs[P.ncell];
+        if (p >= n_live) { pairs[p] = ((u64)FS_DEAD_KEY << 32) | (u64)p; owned[p] = 0; return; }
+    }
     const uint32_t src = slot_src[p];
-    const uint32_t kk = key[src];
-    const uint32_t k = kk < ncell ? kk : ncell - 1u;
+    const uint32_t key = (uint32_t)(kt[src] >> 32);
+    const uint32_t k = key < P.ncell ? key : P.ncell - 1u;
     const uint32_t lo = cs[k], hi = cs[k + 1u];
     uint32_t rank = 0;
     for (uint32_t q = lo; q < hi; ++q) rank += slot_src[q] < src ? 1u : 0u;
-    pairs[lo + rank] = ((u64)kk << 32) | (u64)src;
+    const uint32_t d = lo + rank;
+    pairs[d] = ((u64)key << 32) | (u64)src;
+    const float2 ps = pos_in[src];
+    const float2 v = vel_in[src];
+    pos_s[d] = ps;
+    vel_s[d] = v;
+    const float2 pd = predict_pos(P, ps, v);     // same expression as the key generation -> same bits
+    pred_s[d] = pd;
+    if (key_s) key_s[d] = key;
+    if (!kin_safe(pd, v)) atomicAnd(&safe[d >> 6], ~(1ull << (d & 63u)));   // rare; words preset to all-ones
+    if (SLAB) {
+        const uint32_t cy = key / P.grid_w;
+        const int32_t cxg = (int32_t)(key - cy * P.grid_w) + P.col_origin;
+        owned[d] = (cxg >= (int32_t)P.own_lo && cxg < (int32_t)P.own_hi) ? 1 : 0;
+    }
+    if (rank == 0u && key < P.ncell) {           // first particle of its cell: compute.wgsl:49-55 (index 0 skipped)
+        if (d != 0u || !P.ref_quirks) start_ref[key] = d;
+    }
 }
 
-void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, u64* pairs, uint32_t* cs, uint32_t* scratch,
-                                uint32_t* gap_counter, uint32_t* n_live_out) {
-    const uint32_t count = ncell + 1u;
-    uint32_t* hist = scratch;
-    uint32_t* cursor = hist + count;
-    uint32_t* key = cursor + ncell;
-    uint32_t* slot_src = key + cap;
-    uint32_t* sums = slot_src + cap;
-    const uint32_t nblocks = (count + CS_TILE - 1) / CS_TILE;
-    const dim3 grid((cap + CS_BLOCK - 1) / CS_BLOCK), block(CS_BLOCK);
-    (void)hipMemsetAsync(hist, 0, ((size_t)count + ncell) * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_cs_hist_pairs, grid, block, 0, st, cap, ncell, pairs, key, hist, gap_counter);
-    hipLaunchKernelGGL(k_cs_scan_reduce, dim3(nblocks), block, 0, st, hist, count, sums);
-    hipLaunchKernelGGL(k_cs_scan_sums, dim3(1), block, 0, st, sums, nblocks);
-    hipLaunchKernelGGL(k_cs_scan_apply, dim3(nblocks), block, 0, st, hist, count, sums, cs);
-    hipLaunchKernelGGL(k_cs_scatter_live, grid, block, 0, st, cap, ncell, key, cs, cursor, slot_src, n_live_out);
-    hipLaunchKernelGGL(k_cs_fixup_live, grid, block, 0, st, cap, ncell, key, cs, slot_src, pairs);
+static inline size_t even(size_t w) { return (w + 1u) & ~(size_t)1u; }
+struct CsLayout { uint32_t *hist, *slot_src, *ticket; u64 *kt, *state; uint32_t scan_blocks; };
+static CsLayout cs_layout(uint32_t* scratch, uint32_t n, uint32_t ncell) {
+    // hist (ncell + 1) | kt (n x u64) | slot_src (n) | scan state (u64 per tile) | tickets
+    CsLayout L;
+    size_t o = 0;
+    L.hist = scratch; o = even((size_t)ncell + 1u);
+    L.kt = (u64*)(scratch + o); o += 2 * (size_t)n;
+    L.slot_src = scratch + o; o = even(o + n);
+    L.scan_blocks = (uint32_t)(((size_t)ncell + 1u + SCAN_TILE - 1) / SCAN_TILE);
+    L.state = (u64*)(scratch + o); o += 2 * (size_t)L.scan_blocks;
+    L.ticket = scratch + o;
+    return L;
+}
+// `ncell_max`: the largest table the handle will ever scan (slab handles move their window).
+size_t counting_sort_scratch_words(uint32_t n, uint32_t ncell_max) {
+    const size_t tiles = ((size_t)ncell_max + 1u + SCAN_TILE - 1) / SCAN_TILE;
+    return even((size_t)ncell_max + 1u) + 2 * (size_t)n + even(n) + 2 * tiles + 16;
+}
+// which words of the scratch must be zero when a handle is created: the histogram and the ticket counters (all of it is simplest)
+u64* counting_sort_kt(uint32_t* scratch, uint32_t n, uint32_t ncell) { return cs_layout(scratch, n, ncell).kt; }
+uint32_t* counting_sort_hist(uint32_t* scratch) { return scratch; }
+
+// Slab mode: kt / hist were filled by k_slab_pack + k_slab_unpack (kernels_slab.hip).
+void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, uint32_t ncell_alloc, uint32_t* cs, uint32_t* scratch,
+                                uint32_t* n_live_out, uint32_t epoch) {
+    const CsLayout L = cs_layout(scratch, cap, ncell_alloc);
+    const uint32_t count = ncell + 1u, tiles = (count + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_lookback, dim3(tiles), dim3(SCAN_BLOCK), 0, st, L.hist, count, cs, L.state, L.ticket, epoch, n_live_out);
+    hipLaunchKernelGGL(k_cs_scatter, dim3((cap + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, cap, ncell, L.kt, cs, L.slot_src);
+}
+void launch_counting_reorder_slab(hipStream_t st, const StepParams& P, uint32_t cap, uint32_t ncell_alloc, uint32_t* scratch, u64* pairs,
+                                  const uint32_t* cs, const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s,
+                                  float2* pred_s, uint32_t* key_s, unsigned char* owned, uint32_t* start_ref,
+                                  unsigned long long* safe, uint32_t* force_defer, uint32_t* force_work_count) {
+    const CsLayout L = cs_layout(scratch, cap, ncell_alloc);
+    hipLaunchKernelGGL(k_cs_fixreorder<true>, dim3((cap + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, P, cap, L.kt, cs,
+                       L.slot_src, pairs, pos_in, vel_in, pos_s, vel_s, pred_s, key_s, owned, start_ref, safe, force_defer, force_work_count);
 }
 
-size_t counting_sort_scratch_words(uint32_t n, uint32_t ncell) {
-    const size_t nblocks = ((size_t)ncell + 1 + CS_TILE - 1) / CS_TILE;
-    // hist (ncell+1) | cursor (ncell) | key (n) | slot_src (n) | block sums
-    return ((size_t)ncell + 1) + ncell + (size_t)n * 2 + nblocks + 16;
-}
-
-void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, u64* pairs,
-                          uint32_t* cs, uint32_t* scratch, uint32_t* gap_counter) {
+void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, uint32_t* cs,
+                          uint32_t* scratch, uint32_t* gap_counter, unsigned long long* safe, uint32_t epoch) {
     const uint32_t n = P.n, ncell = P.ncell, count = ncell + 1u;
-    uint32_t* hist = scratch;
-    uint32_t* cursor = hist + count;
-    uint32_t* key = cursor + ncell;
-    uint32_t* slot_src = key + n;
-    uint32_t* sums = slot_src + n;
-    const uint32_t nblocks = (count + CS_TILE - 1) / CS_TILE;
-    (void)hipMemsetAsync(hist, 0, ((size_t)count + ncell) * sizeof(uint32_t), st);      // hist + cursor
-    hipLaunchKernelGGL(k_cs_hist, dim3((n + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, P, pos, vel, key, hist,
-                       gap_counter);
-    hipLaunchKernelGGL(k_cs_scan_reduce, dim3(nblocks), dim3(CS_BLOCK), 0, st, hist, count, sums);
-    hipLaunchKernelGGL(k_cs_scan_sums, dim3(1), dim3(CS_BLOCK), 0, st, sums, nblocks);
-    hipLaunchKernelGGL(k_cs_scan_apply, dim3(nblocks), dim3(CS_BLOCK), 0, st, hist, count, sums, cs);
-    hipLaunchKernelGGL(k_cs_scatter, dim3((n + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, n, ncell, key, cs,
-                       cursor, slot_src);
-    hipLaunchKernelGGL(k_cs_fixup, dim3((n + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, n, ncell, key, cs,
-                       slot_src, pairs);
+    const CsLayout L = cs_layout(scratch, n, ncell);
+    const dim3 grid((n + CS_BLOCK - 1) / CS_BLOCK), block(CS_BLOCK);
+    hipLaunchKernelGGL(k_cs_hist, grid, block, 0, st, P, pos, vel, L.kt, L.hist, gap_counter, safe);
+    hipLaunchKernelGGL(k_scan_lookback, dim3((count + SCAN_TILE - 1) / SCAN_TILE), dim3(SCAN_BLOCK), 0, st, L.hist, count, cs, L.state, L.ticket,
+                       epoch, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_cs_scatter, grid, block, 0, st, n, ncell, L.kt, cs, L.slot_src);
+}
+void launch_counting_reorder(hipStream_t st, const StepParams& P, uint32_t* scratch, u64* pairs, const uint32_t* cs,
+                             const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s,
+                             uint32_t* key_s, uint32_t* start_ref, unsigned long long* safe, uint32_t* force_defer,
+                             uint32_t* force_work_count) {
+    const CsLayout L = cs_layout(scratch, P.n, P.ncell);
+    hipLaunchKernelGGL(k_cs_fixreorder<false>, dim3((P.n + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, P, P.n, L.kt, cs,
+                       L.slot_src, pairs, pos_in, vel_in, pos_s, vel_s, pred_s, key_s, (unsigned char*)nullptr, start_ref, safe,
+                       force_defer, force_work_count);
 }
 
 }  // namespace fsd

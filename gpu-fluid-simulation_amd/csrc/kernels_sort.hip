@@ -211,7 +211,20 @@ __device__ __forceinline__ void lt_tail(const u64* __restrict__ pairs, uint32_t 
 // KEYGEN (2D engine): the init pass also IS predict_next_position + create_spatial_lookup
 // (compute.wgsl:8-42): it reads pos/vel and builds the (key, index) pairs on the fly instead of
 // reading them — one launch and one write+read of the pair array less per step.
-template <bool INIT, bool KEYGEN, int GB>
+// KEYGEN: 0 = the pairs exist, 1 = 2D (StepParams, float2 pos / vel), 2 = 3D (KeyGen3 in the first words of the
+// StepParams argument, float4 pos / vel: the expressions of sim3d.hip predict3 / cell3, bit for bit).
+__device__ __forceinline__ u64 keygen3(const KeyGen3& K, const float4* __restrict__ pos, const float4* __restrict__ vel, uint32_t i) {
+    const float4 p = pos[i], v = vel[i];
+    float rx = p.x + v.x * K.dt, ry = p.y + v.y * K.dt, rz = p.z + v.z * K.dt;
+    if (fabsf(rx) > K.bx) rx = K.bx * sign_f32(rx);
+    if (fabsf(ry) > K.by) ry = K.by * sign_f32(ry);
+    if (fabsf(rz) > K.bz) rz = K.bz * sign_f32(rz);
+    const uint32_t cx = f32_to_u32_sat(floorf(__fdiv_rn(rx + K.bx, K.h))) + 1u;
+    const uint32_t cy = f32_to_u32_sat(floorf(__fdiv_rn(ry + K.by, K.h))) + 1u;
+    const uint32_t cz = f32_to_u32_sat(floorf(__fdiv_rn(rz + K.bz, K.h))) + 1u;
+    return ((u64)((cz * K.gh + cy) * K.gw + cx) << 32) | (u64)i;
+}
+template <bool INIT, int KEYGEN, int GB>
 __global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_local(u64* __restrict__ pairs, uint32_t n,
                                                                    uint32_t num_stages, uint32_t* __restrict__ dirty,
                                                                    StepParams P, const float2* __restrict__ pos,
@@ -229,16 +242,19 @@ __global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_local(u64* __restri
     }
     u64 x[E];
     if (INIT) {
-        if (KEYGEN && blockIdx.x == 0 && t == 0) *gap_counter = 0;      // consumed by k_reorder later in the stream
+        if (KEYGEN != 0 && blockIdx.x == 0 && t == 0) *gap_counter = 0;      // consumed by k_reorder later in the stream
         // coalesced load, straight into LDS, then the group-0 view
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const uint32_t j = ((uint32_t)r << LT<GB>::TOPB) | t;
             u64 v = ~0ull;
             if (base + j < n) {
-                if (KEYGEN) {
+                if (KEYGEN == 1) {
                     const uint32_t i = base + j;
                     v = ((u64)cell_of_point(P, predict_pos(P, pos[i], vel[i])) << 32) | (u64)i;
+                } else if (KEYGEN == 2) {
+                    v = keygen3(*reinterpret_cast<const KeyGen3*>(&P), reinterpret_cast<const float4*>(pos),
+                                reinterpret_cast<const float4*>(vel), base + j);
                 } else {
                     v = pairs[base + j];
                 }
@@ -682,16 +698,17 @@ static int launch_stage(hipStream_t st, u64* pairs, uint32_t n, uint32_t p2, uin
     StepParams P0;
     memset(&P0, 0, sizeof P0);
     if (sort_gb(tiles) == 3)
-        hipLaunchKernelGGL((k_bitonic_local<false, false, 3>), dim3(tiles), dim3(LT<3>::THREADS), 0, st, pairs, n, 0u, dirty, P0,
+        hipLaunchKernelGGL((k_bitonic_local<false, 0, 3>), dim3(tiles), dim3(LT<3>::THREADS), 0, st, pairs, n, 0u, dirty, P0,
                            (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr, gate, glo, ghi);
     else
-        hipLaunchKernelGGL((k_bitonic_local<false, false, 4>), dim3(tiles), dim3(LT<4>::THREADS), 0, st, pairs, n, 0u, dirty, P0,
+        hipLaunchKernelGGL((k_bitonic_local<false, 0, 4>), dim3(tiles), dim3(LT<4>::THREADS), 0, st, pairs, n, 0u, dirty, P0,
                            (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr, gate, glo, ghi);
     return launches + 1;
 }
 
 int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty, const StepParams* keygen,
-                        const float2* pos, const float2* vel, uint32_t* gap_counter, const SortPlan* plan) {
+                        const float2* pos, const float2* vel, uint32_t* gap_counter, const SortPlan* plan,
+                        const KeyGen3* keygen3d, const float4* pos4, const float4* vel4) {
     const int fuse_stage = plan ? plan->fuse_stage : -1;
     const bool one_fallback = plan && plan->fallback == 1;
     if (n <= 1) return 0;
@@ -706,9 +723,16 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
 #define FS_LAUNCH_INIT(KG, GBV, PP, POS, VEL, GC)                                                                      \
     hipLaunchKernelGGL((k_bitonic_local<true, KG, GBV>), dim3(tiles), dim3(LT<GBV>::THREADS), 0, st, pairs, n, init_stages, \
                        dirty, PP, POS, VEL, GC, (const uint32_t*)nullptr, 0u, 0u)
-    if (keygen) { if (gb == 3) FS_LAUNCH_INIT(true, 3, *keygen, pos, vel, gap_counter); else FS_LAUNCH_INIT(true, 4, *keygen, pos, vel, gap_counter); }
-    else if (gb == 3) FS_LAUNCH_INIT(false, 3, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
-    else FS_LAUNCH_INIT(false, 4, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
+    if (keygen) { if (gb == 3) FS_LAUNCH_INIT(1, 3, *keygen, pos, vel, gap_counter); else FS_LAUNCH_INIT(1, 4, *keygen, pos, vel, gap_counter); }
+    else if (keygen3d) {
+        static_assert(sizeof(KeyGen3) <= sizeof(StepParams), "KeyGen3 rides in the StepParams argument");
+        memcpy(&P0, keygen3d, sizeof(KeyGen3));
+        if (gb == 3) FS_LAUNCH_INIT(2, 3, P0, (const float2*)pos4, (const float2*)vel4, gap_counter);
+        else FS_LAUNCH_INIT(2, 4, P0, (const float2*)pos4, (const float2*)vel4, gap_counter);
+        memset(&P0, 0, sizeof P0);
+    }
+    else if (gb == 3) FS_LAUNCH_INIT(0, 3, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
+    else FS_LAUNCH_INIT(0, 4, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
 #undef FS_LAUNCH_INIT
     ++launches;                                         // leaves every tile sorted and its flag cleared
     const int skip_from = sort_skip_stage();

@@ -33,6 +33,7 @@ struct Params3 {
     uint32_t frame;
     ConstDiv div_2h3, div_h2;    // exact constant divisions, proven at create (fs_device.h div_const)
     int32_t share_div;           // one reciprocal per denominator + div_by_rcp in the force pass (fs_device.h)
+    int32_t handoff;             // k3_density stores its nine 64-bit pass masks per particle, k3_force walks them (no second scan)
 };
 
 #define B3 256
@@ -115,12 +116,70 @@ __device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
 }
 
 #define TILE3 384            // staged candidates per sweep row; one z-plane (3 rows) is staged at a time
+#define TILE3_PAD 64u        // the wave-uniform scan reads up to the wave's longest row past a lane's own range
+#define TILE3_ROW (TILE3 + TILE3_PAD)
+typedef unsigned long long u64m;
+
+// ---- pass masks of one staged z-plane -----------------------------------------------------------------------
+// A 3D row of three cells holds ~24 candidates at rest (8 particles per cell) and passes 32 as soon as the column
+// compresses, so the pass masks are 64 bits: v_cmp + two v_addc_co per candidate shift `!(r2 > h^2)` into a register
+// pair (see kernels_step.hip force_sweep_masks for the 2D, 32-bit form).  Candidate t of a row ends up at bit 63 - t.
+// Valid for waves whose three rows hold <= 64 candidates each; the rows are read from the LDS stage `s_flat`
+// (TILE3_ROW entries per row).  Both the density and the force pass need exactly these masks: k3_density computes
+// them, walks them for its own sum and (Params3::handoff) stores them — 72 B per particle — so that k3_force does not
+// scan the 216 candidates a second time (~2 600 of its ~9 900 VALU instructions per wave).
+__device__ __forceinline__ void shift_in_not_greater64(uint32_t& lo, uint32_t& hi, float r2, float lim) {
+    asm("v_cmp_nlt_f32 vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+        : "+v"(lo), "+v"(hi) : "v"(r2), "s"(lim) : "vcc");
+}
+__device__ __forceinline__ void scan3_plane(const Params3& P, const RowRanges& R, const uint32_t* blo, float4 me,
+                                            const float4* s_flat, u64m m[3], uint32_t la[3]) {
+    const float lim = P.h2;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t len = R.hi[r] - R.lo[r];                           // <= 64 (caller)
+        la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
+        const float4* base = s_flat + la[r];
+        uint32_t mlo = 0, mhi = 0, t = 0;
+        for (; __any(t < len); t += 4u) {                                 // t is wave-uniform
+            const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
+            const float4 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
+                shift_in_not_greater64(mlo, mhi, ox * ox + oy * oy + oz * oz, lim);
+            }
+        }
+        // candidate t sits at bit (trips - 1 - t): left-align, keep the lane's own len candidates
+        u64m mask = ((u64m)mhi << 32) | mlo;
+        mask = t ? mask << (64u - t) : 0ull;
+        mask &= len ? ~0ull << (64u - len) : 0ull;
+        m[r] = mask;
+    }
+}
+// Is the mask form available for this wave's plane?  k3_density and k3_force must agree, so both call this with the
+// RowRanges / block bounds they derive from the same cell table.
+__device__ __forceinline__ bool plane_masked(const RowRanges& R, bool fit) {
+    const bool long_row = R.hi[0] - R.lo[0] > 64u || R.hi[1] - R.lo[1] > 64u || R.hi[2] - R.lo[2] > 64u;
+    return fit && !__any(long_row);
+}
+
+__device__ __forceinline__ float dens3_tol(const Params3& P, float4 me, float4 q, float acc) {
+    const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
+    const float r2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+    const float t = fmaxf(P.h2 - r2, 0.0f);                               // NaN candidate: contributes nothing
+    return __builtin_fmaf(t * t, t, acc);
+}
 
 // The 27-cell sweep runs plane by plane (z outer): per plane the workgroup's three row ranges are
-// staged into LDS with coalesced loads (fs_device.h block_tile_bounds), the lanes loop over LDS.
+// staged into LDS with coalesced loads (fs_device.h block_tile_bounds).  Waves whose rows fit the 64-bit masks
+// scan the plane into masks and add the terms of the set bits (row 0, 1, 2, ascending: the oracle's order — the
+// candidates outside the radius contribute +0 there, which changes no bit of a non-negative sum); other waves loop
+// over their candidates directly.  MODE 2 (FS_MATH_TOLERANCE): FMA terms, the constant applied once.
+template <int MODE>
 __global__ __launch_bounds__(B3) void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs,
-                                                 float4* __restrict__ vel_s) {
-    __shared__ float4 s_pred[3][TILE3];
+                                                 float4* __restrict__ vel_s, u64m* __restrict__ masks) {
+    __shared__ float4 s_pred[3 * TILE3_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t i = blockIdx.x * B3 + threadIdx.x;
     const bool live = i < P.n;
@@ -147,38 +206,66 @@ __global__ __launch_bounds__(B3) void k3_density(Params3 P, float4* __restrict__
         if (fit) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
-                for (uint32_t j = threadIdx.x; j < bhi[r] - blo[r]; j += B3) s_pred[r][j] = pred[blo[r] + j];
+                for (uint32_t j = threadIdx.x; j < bhi[r] - blo[r]; j += B3) s_pred[r * TILE3_ROW + j] = pred[blo[r] + j];
             __syncthreads();
+            if (plane_masked(R, fit)) {
+                u64m m[3];
+                uint32_t la[3];
+                scan3_plane(P, R, blo, me, s_pred, m, la);
+                if (P.handoff && live) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const bool any = R.lo[r] < R.hi[r];
-                const uint32_t hi = any ? R.hi[r] - blo[r] : 0u;
-                uint32_t k = any ? R.lo[r] - blo[r] : 0u;
-                for (; k + 4u <= hi; k += 4u) {
-                    const float t0 = dens3(P, me, s_pred[r][k]), t1 = dens3(P, me, s_pred[r][k + 1u]);
-                    const float t2 = dens3(P, me, s_pred[r][k + 2u]), t3 = dens3(P, me, s_pred[r][k + 3u]);
-                    rho += t0; rho += t1; rho += t2; rho += t3;
+                    for (int r = 0; r < 3; ++r) masks[(size_t)(plane * 3 + r) * P.n + i] = m[r];
                 }
-                for (; k < hi; ++k) rho += dens3(P, me, s_pred[r][k]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    u64m mm = m[r];
+                    const float4* base = s_pred + la[r];
+                    while (mm) {
+                        const uint32_t t = (uint32_t)__builtin_clzll(mm);
+                        mm ^= 0x8000000000000000ull >> t;
+                        if (MODE == 2) rho = dens3_tol(P, me, base[t], rho);
+                        else rho += dens3(P, me, base[t]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const bool any = R.lo[r] < R.hi[r];
+                    const uint32_t hi = any ? R.hi[r] - blo[r] : 0u;
+                    uint32_t k = any ? R.lo[r] - blo[r] : 0u;
+                    const float4* sp = s_pred + r * TILE3_ROW;
+                    if (MODE == 2) { for (; k < hi; ++k) rho = dens3_tol(P, me, sp[k], rho); continue; }
+                    for (; k + 4u <= hi; k += 4u) {
+                        const float t0 = dens3(P, me, sp[k]), t1 = dens3(P, me, sp[k + 1u]);
+                        const float t2 = dens3(P, me, sp[k + 2u]), t3 = dens3(P, me, sp[k + 3u]);
+                        rho += t0; rho += t1; rho += t2; rho += t3;
+                    }
+                    for (; k < hi; ++k) rho += dens3(P, me, sp[k]);
+                }
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
-                for (uint32_t k = R.lo[r]; k < R.hi[r]; ++k) rho += dens3(P, me, pred[k]);
+                for (uint32_t k = R.lo[r]; k < R.hi[r]; ++k) {
+                    if (MODE == 2) rho = dens3_tol(P, me, pred[k], rho);
+                    else rho += dens3(P, me, pred[k]);
+                }
         }
         __syncthreads();     // the next plane reuses s_pred / s_red
     }
     if (!live) return;
+    if (MODE == 2) rho = rho * (P.mass * P.poly6);                 // sum of (h2 - r2)^3 -> density
     rho = fmaxf(rho, 1.19209290e-07f);
     rho = fmaxf(rho, 0.1f);
     reinterpret_cast<float*>(pred + i)[3] = rho;                   // pred.w <- density (other lanes read .xyz only)
     // vel_s.w <- +-RN(1/rho): what the force pass divides by, once per particle instead of once per pair; positive only
     // when every operand this particle brings to a pair is inside the proven quotient ranges (fs_device.h)
     float* yw = reinterpret_cast<float*>(vel_s + i) + 3;
+    const float y = (P.share_div && rho <= FS_RCP_HI) ? rcp_rn_fast(rho) : __fdiv_rn(1.0f, rho);
+    if (MODE == 2) { *yw = y; return; }                            // tolerance mode: no classification, the force pass has no exact quotients
     const bool ksafe = *yw > 0.0f;
     const float press = P.pressure_k * (rho - P.rest_density);     // the expression the force pass evaluates
     const bool ok = ksafe && rho <= FS_RCP_HI && fabsf(press) <= FS_PRESSURE_HI;
-    const float y = (P.share_div && rho <= FS_RCP_HI) ? rcp_rn_fast(rho) : __fdiv_rn(1.0f, rho);
     *yw = ok ? y : -y;
 }
 
@@ -560,6 +647,7 @@ struct fs_sim3 {
     fs3_settings st{};
     uint32_t n = 0, gw = 0, gh = 0, gd = 0, ncell = 0, tick = 0, work_cap = 0;
     int device = 0;
+    int math_mode = FS_MATH_IEEE;
     hipStream_t stream = nullptr;
     Dev3<float4> pos, vel, pos_s, vel_s, pred;
     Dev3<uint32_t> key, cs, counter, dirty;
@@ -663,8 +751,14 @@ fs_status fs3_reference_lattice(const fs3_settings* st, fs_vec3 off, fs3_particl
 }
 
 fs_status fs3_create(const fs3_settings* st, int device, fs_vec3 off, fs_sim3** out) {
+    return fs3_create_ex(st, device, off, FS_MATH_IEEE, out);
+}
+
+fs_status fs3_create_ex(const fs3_settings* st, int device, fs_vec3 off, int math_mode, fs_sim3** out) {
     if (!st || !out) return fail3(FS_ERR_INVALID, "null argument");
     *out = nullptr;
+    if (math_mode != FS_MATH_IEEE && math_mode != FS_MATH_TOLERANCE)
+        return fail3(FS_ERR_UNSUPPORTED, "3D math_mode must be FS_MATH_IEEE or FS_MATH_TOLERANCE");
     if (st->particle_count <= 1) return fail3(FS_ERR_INVALID, "particle_count <= 1");
     if (st->particle_count > (1u << 28)) return fail3(FS_ERR_INVALID, "particle_count > 2^28 (32-bit byte offsets)");
     if (!(st->smoothing_radius > 0.0f) || !(st->size.x > 0) || !(st->size.y > 0) || !(st->size.z > 0))
@@ -680,7 +774,7 @@ fs_status fs3_create(const fs3_settings* st, int device, fs_vec3 off, fs_sim3** 
     H3(hipSetDevice(device));
     fs_sim3* s = new (std::nothrow) fs_sim3();
     if (!s) return fail3(FS_ERR_OOM, "host allocation failed");
-    s->st = *st; s->n = st->particle_count; s->device = device;
+    s->st = *st; s->n = st->particle_count; s->device = device; s->math_mode = math_mode;
     s->gw = (uint32_t)((size_t)std::ceil(st->size.x / st->smoothing_radius) + 2);
     s->gh = (uint32_t)((size_t)std::ceil(st->size.y / st->smoothing_radius) + 2);
     s->gd = (uint32_t)((size_t)std::ceil(st->size.z / st->smoothing_radius) + 2);

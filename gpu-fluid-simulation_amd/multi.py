@@ -249,6 +249,40 @@ class HipSlabEngine:
     def max_speed(self):
         return self.sim.max_speed()
 
+    def rebalance_inputs(self, gw):
+        """(column histogram summed over ranks as int64[gw], [lost, overflow, far_halo, vmax] maxed over ranks) with ONE
+        device read: fs_slab_rebalance_stats leaves both on the device, the two all-reduces run on the simulation's
+        stream (fs_comm_allreduce with the native transport, torch.distributed on the same stream with nccl), and the
+        host reads the reduced buffer once.  Host transport (gloo): one device read, then the all-reduces on the host."""
+        g, t = self.g, self.t
+        torch_cuda = self.cuda and not isinstance(t, NativeTransport)
+        if getattr(self, "_reb", None) is None or self._reb_gw != gw:
+            self._reb_gw = gw
+            if torch_cuda:
+                self._reb = t.torch.zeros(gw + 4, dtype=t.torch.int32, device=t.device)
+            else:
+                self._reb = g.ResizableBuffer("rebalance", np.uint32, gw + 4, device=self.sim.device_index)
+        base = self._reb.data_ptr() if torch_cuda else self._reb.device_ptr
+        self.sim.rebalance_stats(C.c_void_p(base + 4 * gw), C.c_void_p(base), gw)
+        if torch_cuda:
+            t.dist.all_reduce(self._reb[:gw], op=t.dist.ReduceOp.SUM)
+            t.dist.all_reduce(self._reb[gw:], op=t.dist.ReduceOp.MAX)
+            host = self._reb.cpu().numpy().view(np.uint32)
+        elif isinstance(t, NativeTransport):
+            lib = t.lib
+            g._check(lib, lib.fs_comm_allreduce(self.sim._h, t.comm, C.c_void_p(base), gw, 0, 0))              # u32, SUM
+            g._check(lib, lib.fs_comm_allreduce(self.sim._h, t.comm, C.c_void_p(base + 4 * gw), 4, 0, 1))       # u32, MAX
+            host = self._reb.read()
+        else:
+            host = self._reb.read()
+            th, ts = t.torch.from_numpy(host[:gw].astype(np.int64)), t.torch.from_numpy(host[gw:].astype(np.int64))
+            t.dist.all_reduce(th, op=t.dist.ReduceOp.SUM)
+            t.dist.all_reduce(ts, op=t.dist.ReduceOp.MAX)
+            host = np.concatenate([th.numpy(), ts.numpy()]).astype(np.uint32)
+        stats = np.array([host[gw], host[gw + 1], host[gw + 2],
+                          float(np.array([host[gw + 3]], dtype=np.uint32).view(np.float32)[0])], dtype=np.float64)
+        return host[:gw].astype(np.int64), stats
+
     def sync(self):
         self.sim.sync()
 
@@ -298,13 +332,19 @@ class SlabDriver:
 
     def rebalance(self):
         dist = self.t.dist
-        hist = self.e.column_histogram(self.grid_w).astype(np.int64)
-        hist = self._allreduce(hist, dist.ReduceOp.SUM)          # tiny (grid_w * 8 B), every K steps only
-        # violations + largest speed of any rank, one more tiny all-reduce (MAX)
-        c = self.e.counters() if (self.check_counters and hasattr(self.e, "counters")) else {}
-        vmax = float(self.e.max_speed()) if hasattr(self.e, "max_speed") else SPEED_CLAMP
-        stats = np.array([c.get("lost", 0), c.get("overflow", 0), c.get("far_halo", 0), vmax], dtype=np.float64)
-        stats = self._allreduce(stats, dist.ReduceOp.MAX)
+        c = {}
+        if hasattr(self.e, "rebalance_inputs"):                  # device-resident engine: two all-reduces, ONE host read
+            hist, stats = self.e.rebalance_inputs(self.grid_w)
+            if not self.check_counters:
+                stats[:3] = 0
+        else:
+            hist = self.e.column_histogram(self.grid_w).astype(np.int64)
+            hist = self._allreduce(hist, dist.ReduceOp.SUM)          # tiny (grid_w * 8 B), every K steps only
+            # violations + largest speed of any rank, one more tiny all-reduce (MAX)
+            c = self.e.counters() if (self.check_counters and hasattr(self.e, "counters")) else {}
+            vmax = float(self.e.max_speed()) if hasattr(self.e, "max_speed") else SPEED_CLAMP
+            stats = np.array([c.get("lost", 0), c.get("overflow", 0), c.get("far_halo", 0), vmax], dtype=np.float64)
+            stats = self._allreduce(stats, dist.ReduceOp.MAX)
         if stats[:3].any():
             raise SlabProtocolError(f"slab protocol violated at step {self.steps}: max over ranks of lost/overflow/far_halo = "
                                     f"{int(stats[0])}/{int(stats[1])}/{int(stats[2])} (this rank: {c})")

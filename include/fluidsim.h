@@ -161,7 +161,13 @@ void fs_destroy(fs_sim* sim);
 /* FluidSimulation::tick (src/simulation.rs:459-539).  Pre-increments `tick`,
  * builds the 120-byte uniform (:470-497) and enqueues the whole pass chain on
  * the simulation's stream.  Non-blocking, like the reference (which only
- * records into a CommandEncoder; submit happens at src/main.rs:226). */
+ * records into a CommandEncoder; submit happens at src/main.rs:226).
+ * FS_ERR_DEVICE from fs_step / fs_timed_steps is terminal for the handle: besides HIP runtime errors it reports that the
+ * sort's stand-by kernel (csrc/kernels_sort.hip k_late_fallback, a persistent launch with a bounded-spin grid barrier)
+ * timed out on a barrier in an EARLIER step — the host learns of it from the device's report a few steps later, and the
+ * particle order of every step since is undefined.  Destroy the handle and re-create it (or re-upload a checkpoint into
+ * a new one); no further call on the old handle is meaningful.  fs_sort_plan_info.timeouts counts such events
+ * (0 on a healthy device: the grid is <= 128 workgroups on 256 CUs, all co-resident). */
 fs_status fs_step(fs_sim* sim, const fs_tick_settings* tick);
 /* device.poll(Wait) equivalent (src/main.rs:79). */
 fs_status fs_sync(fs_sim* sim);
@@ -304,6 +310,12 @@ fs_status fs_slab_max_speed(fs_sim* sim, float* out);
 /* Per-global-column particle counts of the owned columns (others untouched); blocking. */
 fs_status fs_slab_column_histogram(fs_sim* sim, uint32_t* hist, size_t grid_w_global);
 
+/* The three re-balancing inputs above without reading anything back: enqueued on the simulation's stream, results stay in
+ * DEVICE buffers of the caller — hist_dev[grid_w_global] (zero outside the owned window) and stats_dev[4] = {lost,
+ * overflow, far_halo, bits of the largest owned |velocity|}, all four MAX-reducible as u32.  All-reduce them on the
+ * same stream (fs_comm_allreduce: SUM for the histogram, MAX for the stats) and read both once. */
+fs_status fs_slab_rebalance_stats(fs_sim* sim, uint32_t* stats_dev, uint32_t* hist_dev, size_t grid_w_global);
+
 /* ---- native RCCL transport (csrc/comm.hip): one process per GPU, any host language --------------------------
  * fs_comm_unique_id on rank 0 -> ship the 128 bytes to every rank -> fs_comm_init everywhere; then per step
  * fs_slab_pack -> fs_slab_exchange -> fs_slab_step.  The exchange is one grouped ncclSend/ncclRecv set on the
@@ -355,6 +367,10 @@ typedef struct fs3_particle {      /* 48 bytes */
 typedef struct fs_sim3 fs_sim3;
 
 fs_status fs3_create(const fs3_settings* settings, int device, fs_vec3 initial_offset, fs_sim3** out);
+/* math_mode: FS_MATH_IEEE (default of fs3_create: bit-identical to oracle/sph_oracle3d.cpp) or FS_MATH_TOLERANCE (density
+ * and force terms re-associated as in 2D: rtol 1e-5 per step against the 3D oracle, cell keys bit-exact).  The 3D
+ * statement has no reference counterpart, so "exact" here means exact against this repository's own 3D oracle. */
+fs_status fs3_create_ex(const fs3_settings* settings, int device, fs_vec3 initial_offset, int math_mode, fs_sim3** out);
 void fs3_destroy(fs_sim3* sim);
 fs_status fs3_step(fs_sim3* sim, const fs3_tick_settings* tick);
 fs_status fs3_sync(fs_sim3* sim);

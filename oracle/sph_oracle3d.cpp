@@ -14,6 +14,9 @@
  * Cell starts are rebuilt cleanly every step (no stale-start quirk: that is a property of the
  * 2D reference only); no mouse force and no obstacle field in 3D.
  * IEEE f32, written association, build with -ffp-contract=off.
+ * OpenMP over particles / over the disjoint pairs of one sort dispatch (orc_set_threads of sph_oracle.cpp
+ * sets the count): every iteration writes its own record only, so results do not depend on the thread count
+ * (the full-size parity tests run it on all host cores).
  */
 #include <algorithm>
 #include <cmath>
@@ -67,6 +70,7 @@ void bitonic(T* v, uint32_t n, K key) {   // the reference network (sort.wgsl:27
     for (uint32_t stage = 0; stage < stages; ++stage)
         for (uint32_t step = 0; step <= stage; ++step) {
             const uint32_t gw = 1u << (stage - step), gh = 2 * gw - 1;
+#pragma omp parallel for schedule(static) if (threads > 65536)      // pairs of one dispatch are disjoint
             for (uint32_t i = 0; i < threads; ++i) {
                 const uint32_t hh = i & (gw - 1), lo = hh + (gh + 1) * (i / gw);
                 const uint32_t hi = lo + (step == 0 ? gh - 2 * hh : (gh + 1) / 2);
@@ -89,6 +93,7 @@ void step3(Sim3& s) {
     const float dt = s.tk.delta, h = s.st.smoothing_radius;
     const float bs[3] = {s.st.size.x * 0.5f, s.st.size.y * 0.5f, s.st.size.z * 0.5f};
     // predict (compute.wgsl:16-26) + key (compute.wgsl:33-42)
+#pragma omp parallel for schedule(static)
     for (uint32_t i = 0; i < n; ++i) {
         fs3_particle& q = s.p[i];
         float* pr = &q.predicted_position.x;
@@ -108,6 +113,7 @@ void step3(Sim3& s) {
         if ((i == 0 || s.p[i].grid != s.p[i - 1].grid) && s.p[i].grid < s.starts.size()) s.starts[s.p[i].grid] = i;
     // density (compute.wgsl:59-74 shape)
     const float h2 = h * h;
+#pragma omp parallel for schedule(dynamic, 1024)
     for (uint32_t i = 0; i < n; ++i) {
         const float* me = &s.p[i].predicted_position.x;
         uint32_t c[3];
@@ -133,6 +139,7 @@ void step3(Sim3& s) {
     // force + integrate (compute.wgsl:79-157 shape), Jacobi snapshot
     s.snap = s.p;
     const std::vector<fs3_particle>& src = s.snap;
+#pragma omp parallel for schedule(dynamic, 1024)
     for (uint32_t i = 0; i < n; ++i) {
         fs3_particle q = src[i];
         const float* me = &q.predicted_position.x;

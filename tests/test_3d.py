@@ -131,3 +131,43 @@ def test_3d_dense_cluster(fs, orc):
     for s in range(2):
         sim.tick(tick); ref.step(tick)
         _assert_equal3(sim.download_particles(), ref.particles(), f"3d cluster step {s}")
+
+
+def test_oracle3d_is_thread_count_independent(fs, orc):
+    """The 3D oracle's OpenMP loops write one record per iteration: 1 thread == all threads, bit for bit."""
+    st, off, tick = fs.dam_break_3d(14 ** 3)
+    outs = []
+    for threads in (1, max(2, min(8, orc.max_threads()))):
+        orc.set_threads(threads)
+        o = orc.OracleSim3D(st, off)
+        rng = np.random.default_rng(4)
+        p = o.particles()
+        p["position"] += rng.uniform(-0.03, 0.03, size=p["position"].shape).astype(np.float32)
+        p["predicted_position"] = p["position"]
+        o.set_particles(p)
+        for _ in range(3):
+            o.step(tick)
+        outs.append(o.particles().copy())
+        orc.set_threads(1)
+    assert np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_3d_8m_full_state_matches_oracle(fs, orc):
+    """BASELINE configs[3] at its full size: one step of the 200^3 dam break on the GPU, EVERY field of EVERY particle
+    bit for bit against the 3D oracle run on all host cores (keys, positions, predicted positions, velocities,
+    densities).  compute.wgsl:45-157 shapes; the 3D statement itself is build-defined (no reference counterpart)."""
+    import bench
+    n = 200 ** 3
+    st, off, tick = fs.dam_break_3d(n)
+    sim = fs.FluidSimulation3D(st, device=0, initial_offset=off)
+    sim.tick(tick)
+    got = sim.download_particles()
+    sim.close()
+    orc.set_threads(min(bench.usable_cores(), orc.max_threads()))
+    try:
+        ref = orc.OracleSim3D(st, off)
+        ref.step(tick)
+        _assert_equal3(got, ref.particles_view(), "3d 8M step 1")
+    finally:
+        orc.set_threads(1)

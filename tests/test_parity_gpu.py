@@ -262,6 +262,32 @@ def test_sort_permutation_16m_matches_network(fs, orc):
     assert np.array_equal(p0["position"][perm].view(np.uint32), p1["predicted_position"].view(np.uint32))
 
 
+def test_16m_full_state_matches_oracle(fs, orc):
+    """BASELINE configs[2] at its full size: two steps of the 16M dam break on the GPU, EVERY field of EVERY particle
+    and the whole start_indices table bit for bit against the oracle (run on all host cores; its results do not
+    depend on the thread count) — compute.wgsl:45-157, sort.wgsl:27-51 at the headline size, not a property check."""
+    import bench
+    n = 1 << 24
+    st, off, tick = fs.dam_break_2d(n)
+    sim = fs.FluidSimulation(st, device=0, initial_offset=off)
+    orc.set_threads(min(bench.usable_cores(), orc.max_threads()))
+    try:
+        ref = orc.OracleSim(st, off)
+        for step in (1, 2):
+            sim.tick(tick)
+            ref.step(tick)
+            got, want = sim.download_particles(), ref.particles_view()
+            assert np.array_equal(got["grid"], want["grid"]), f"16M step {step}: cell keys differ"
+            for f in ("position", "predicted_position", "velocity", "density"):
+                a, b = got[f].view(np.uint32), want[f].view(np.uint32)
+                assert np.array_equal(a, b), f"16M step {step}: {f} not bit-exact ({int((a != b).sum())} words differ)"
+            assert np.array_equal(sim.download_start_indices(), ref.start_indices_view()), f"16M step {step}: start_indices"
+            del got
+    finally:
+        orc.set_threads(1)
+    sim.close()
+
+
 def test_16m_properties(fs):
     """Size-independent properties at the headline size: sortedness, start_indices
     consistency, permutation (multiset of lattice x-coordinates preserved), finite state."""
