@@ -25,6 +25,7 @@ namespace fsd {
 #define SORT_LOG_T 12
 #define SORT_T (1u << SORT_LOG_T)
 #define SORT_THREADS 256
+#define FS_TILE_WIDE 2u      // dirty[tile]: the packed first kernel left this tile to the 64-bit one (k_bitonic_local32)
 
 // ------------------------------------------------------------------ tile-local kernels
 // Register-blocked: 2^(12-GB) threads x E = 2^GB elements.  The 12 index bits of a tile are split in groups of GB;
@@ -74,10 +75,16 @@ __device__ __forceinline__ uint32_t lt_idx(uint32_t r, uint32_t t) {
 __device__ __forceinline__ void lt_cx(u64& lo, u64& hi) {     // lo = physically lower element
     if ((uint32_t)(lo >> 32) > (uint32_t)(hi >> 32)) { const u64 t = lo; lo = hi; hi = t; }
 }
+// Packed form of the first kernel (k_bitonic_local32): one 32-bit word per element, (key - tile_min) << 12 | position in
+// the tile.  key(a) > key(b)  <=>  a > (b | 0xFFF): with equal keys a <= key << 12 | 0xFFF, with key(a) > key(b)
+// a >= (key(b) + 1) << 12.  Equal keys never swap, exactly as in the 64-bit form: 4 VALU instead of 5, half the LDS.
+__device__ __forceinline__ void lt_cx(uint32_t& lo, uint32_t& hi) {
+    if (lo > (hi | 0xFFFu)) { const uint32_t t = lo; lo = hi; hi = t; }
+}
 
 // Steps on in-thread bits TOP..0 of a group.  FLIP: the step on bit TOP is a stage's mirror step.
-template <int GB, int TOP, bool FLIP>
-__device__ __forceinline__ void lt_round(u64 (&x)[1 << GB]) {
+template <int GB, int TOP, bool FLIP, class T>
+__device__ __forceinline__ void lt_round(T (&x)[1 << GB]) {
 #pragma unroll
     for (int b = TOP; b >= 0; --b) {
 #pragma unroll
@@ -90,8 +97,8 @@ __device__ __forceinline__ void lt_round(u64 (&x)[1 << GB]) {
     }
 }
 
-template <int GB, int B, int TOP, bool FLIP>
-__device__ __forceinline__ void lt_read(const u64* s, u64 (&x)[1 << GB], uint32_t t) {
+template <int GB, int B, int TOP, bool FLIP, class T>
+__device__ __forceinline__ void lt_read(const T* s, T (&x)[1 << GB], uint32_t t) {
 #pragma unroll
     for (int r = 0; r < (1 << GB); ++r) {
         uint32_t idx = lt_idx<GB, B>((uint32_t)r, t);
@@ -100,8 +107,8 @@ __device__ __forceinline__ void lt_read(const u64* s, u64 (&x)[1 << GB], uint32_
     }
 }
 
-template <int GB, int B, int TOP, bool FLIP>
-__device__ __forceinline__ void lt_write(u64* s, const u64 (&x)[1 << GB], uint32_t t) {
+template <int GB, int B, int TOP, bool FLIP, class T>
+__device__ __forceinline__ void lt_write(T* s, const T (&x)[1 << GB], uint32_t t) {
 #pragma unroll
     for (int r = 0; r < (1 << GB); ++r) {
         uint32_t idx = lt_idx<GB, B>((uint32_t)r, t);
@@ -125,8 +132,8 @@ __device__ __forceinline__ void lt_sync() {
 }
 
 // From group G (just written to LDS in its layout) down to group 0: the remaining plain steps of a stage or tail.
-template <int GB, int G>
-__device__ __forceinline__ void lt_descend(u64* s, u64 (&x)[1 << GB], uint32_t t) {
+template <int GB, int G, class T>
+__device__ __forceinline__ void lt_descend(T* s, T (&x)[1 << GB], uint32_t t) {
     if constexpr (G > 0) {
         lt_sync<GB, G>();
         lt_read<GB, (G - 1) * GB, GB - 1, false>(s, x, t);
@@ -139,8 +146,8 @@ __device__ __forceinline__ void lt_descend(u64* s, u64 (&x)[1 << GB], uint32_t t
 }
 
 // Stage S (0..11) of the network inside a tile; on entry and exit the tile is in the group-0 layout, in registers.
-template <int GB, int S>
-__device__ __forceinline__ void lt_stage(u64* s, u64 (&x)[1 << GB], uint32_t t) {
+template <int GB, int S, class T>
+__device__ __forceinline__ void lt_stage(T* s, T (&x)[1 << GB], uint32_t t) {
     constexpr int G = S / GB, TOP = S % GB;
     if constexpr (G == 0) {
 #pragma unroll
@@ -242,6 +249,9 @@ __global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_local(u64* __restri
     }
     u64 x[E];
     if (INIT) {
+        // gate == dirty, gate_lo == 2 (launch_bitonic_sort): this launch only serves the tiles the packed kernel
+        // (k_bitonic_local32) could not take — their flag is FS_TILE_WIDE; anything else returns at once
+        if (gate_lo == FS_TILE_WIDE && gate && gate[blockIdx.x] != FS_TILE_WIDE) return;
         if (KEYGEN != 0 && blockIdx.x == 0 && t == 0) *gap_counter = 0;      // consumed by k_reorder later in the stream
         // coalesced load, straight into LDS, then the group-0 view
 #pragma unroll
@@ -295,6 +305,107 @@ __global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_local(u64* __restri
     }
     lt_store<GB>(pairs, s, x, base, t, n);
     if (t == 0) dirty[blockIdx.x] = 0;                 // sorted again
+}
+
+// ---- the first kernel in PACKED form --------------------------------------------------------------------------------
+// Stages 0..11 of a tile only ever compare keys and move (key, index) pairs INSIDE the tile, and the index is
+// base + position: one 32-bit word (key - tile_min) << 12 | position carries the same information whenever the keys of
+// the tile span less than 2^20 — always, for a state that was in cell order one step ago (a tile of 4096 particles covers
+// ~1000 cells plus at most a few row ends; an uploaded, shuffled state does not, see FS_TILE_WIDE).  Half the LDS per
+// tile (17.4 KB: 8 tiles per CU instead of 4 — the round-2 kernel sat at 3 waves per SIMD with its load, network and
+// store phases adding up instead of overlapping), half the registers, half the LDS traffic, and a compare-exchange of
+// 4 instructions instead of 5 (lt_cx).  The pairs are rebuilt at the store.  Same network, same strict compare on
+// keys only: the arrangement — ties included — is bit for bit the 64-bit kernel's (tests/test_sort_gpu.py).
+// Tiles whose keys span 2^20 or more are left untouched and flagged FS_TILE_WIDE in `dirty`; the 64-bit kernel follows
+// in the stream and takes exactly those (an idle launch otherwise).
+template <int KEYGEN, int GB>
+__global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_local32(u64* __restrict__ pairs, uint32_t n,
+                                                                     uint32_t num_stages, uint32_t* __restrict__ dirty,
+                                                                     StepParams P, const float2* __restrict__ pos,
+                                                                     const float2* __restrict__ vel,
+                                                                     uint32_t* __restrict__ gap_counter) {
+    constexpr int E = LT<GB>::E;
+    __shared__ uint32_t s[LT<GB>::LDS];
+    __shared__ uint32_t s_mm[2 * (LT<GB>::THREADS / 64)];
+    const uint32_t base = blockIdx.x * SORT_T;
+    const uint32_t t = threadIdx.x;
+    if (KEYGEN != 0 && blockIdx.x == 0 && t == 0) *gap_counter = 0;      // consumed by k_reorder later in the stream
+    uint32_t key[E];
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {                                        // coalesced: position j = r << TOPB | t
+        const uint32_t j = ((uint32_t)r << LT<GB>::TOPB) | t;
+        uint32_t k = 0xFFFFFFFFu;                                        // padding sorts last (as ~0ull does in the 64-bit form)
+        if (base + j < n) {
+            if (KEYGEN == 1) k = cell_of_point(P, predict_pos(P, pos[base + j], vel[base + j]));
+            else if (KEYGEN == 2) k = (uint32_t)(keygen3(*reinterpret_cast<const KeyGen3*>(&P), reinterpret_cast<const float4*>(pos),
+                                                         reinterpret_cast<const float4*>(vel), base + j) >> 32);
+            kmin = k < kmin ? k : kmin;
+            kmax = k > kmax ? k : kmax;
+        }
+        key[r] = k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if ((t & 63u) == 0) { s_mm[2 * (t >> 6)] = kmin; s_mm[2 * (t >> 6) + 1] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < LT<GB>::THREADS / 64; ++w) {
+        const uint32_t a = s_mm[2 * w], b = s_mm[2 * w + 1];
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    static_assert(KEYGEN == 1 || KEYGEN == 2, "the packed form builds the pairs itself: index = base + position");
+    if (kmax - kmin >= (1u << 20) - 1u) {                                // uniform; 0xFFFFF is reserved for the padding
+        if (t == 0) dirty[blockIdx.x] = FS_TILE_WIDE;
+        return;
+    }
+    uint32_t x[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t j = ((uint32_t)r << LT<GB>::TOPB) | t;
+        const uint32_t rel = key[r] == 0xFFFFFFFFu ? 0xFFFFFu : key[r] - kmin;
+        s[lt_pad<GB>(j)] = (rel << 12) | j;
+    }
+    __syncthreads();
+    lt_read<GB, 0, GB - 1, false>(s, x, t);
+    bool sorted_already;
+    {   // a tile whose keys are already in order passes through the network unchanged (see k_bitonic_local)
+        int ok = 1;
+#pragma unroll
+        for (int r = 0; r + 1 < E; ++r) ok &= (x[r] >> 12) <= (x[r + 1] >> 12);
+        if (t + 1u < (uint32_t)LT<GB>::THREADS) ok &= (x[E - 1] >> 12) <= (s[lt_pad<GB>((t + 1u) << GB)] >> 12);
+        sorted_already = __syncthreads_and(ok) != 0;
+    }
+    if (!sorted_already) {
+        lt_stage<GB, 0>(s, x, t);
+        if (num_stages > 1) lt_stage<GB, 1>(s, x, t);
+        if (num_stages > 2) lt_stage<GB, 2>(s, x, t);
+        if (num_stages > 3) lt_stage<GB, 3>(s, x, t);
+        if (num_stages > 4) lt_stage<GB, 4>(s, x, t);
+        if (num_stages > 5) lt_stage<GB, 5>(s, x, t);
+        if (num_stages > 6) lt_stage<GB, 6>(s, x, t);
+        if (num_stages > 7) lt_stage<GB, 7>(s, x, t);
+        if (num_stages > 8) lt_stage<GB, 8>(s, x, t);
+        if (num_stages > 9) lt_stage<GB, 9>(s, x, t);
+        if (num_stages > 10) lt_stage<GB, 10>(s, x, t);
+        if (num_stages > 11) lt_stage<GB, 11>(s, x, t);
+        lt_write<GB, 0, GB - 1, false>(s, x, t);           // back to LDS at the natural positions
+    }
+    __syncthreads();
+    lt_read<GB, LT<GB>::TOPB, GB - 1, false>(s, x, t);     // the coalesced layout: 512 contiguous bytes per wave store
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t j = ((uint32_t)r << LT<GB>::TOPB) | t;
+        if (base + j < n) {
+            pairs[base + j] = ((u64)(kmin + (x[r] >> 12)) << 32) | (u64)(base + (x[r] & 0xFFFu));
+        }
+    }
+    if (t == 0) dirty[blockIdx.x] = 0;
 }
 
 // Stage 12 in ONE kernel: its only global step is the mirror step between the two tiles of an 8192-block, so a
@@ -723,14 +834,36 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
 #define FS_LAUNCH_INIT(KG, GBV, PP, POS, VEL, GC)                                                                      \
     hipLaunchKernelGGL((k_bitonic_local<true, KG, GBV>), dim3(tiles), dim3(LT<GBV>::THREADS), 0, st, pairs, n, init_stages, \
                        dirty, PP, POS, VEL, GC, (const uint32_t*)nullptr, 0u, 0u)
-    if (keygen) { if (gb == 3) FS_LAUNCH_INIT(1, 3, *keygen, pos, vel, gap_counter); else FS_LAUNCH_INIT(1, 4, *keygen, pos, vel, gap_counter); }
+    // engines' steps (the pairs are built here): the packed kernel first, then the 64-bit kernel for the tiles it flagged
+    // FS_TILE_WIDE (an idle launch in a running simulation).  FS_SORT_PACKED=0: the 64-bit kernel alone, as in round 2.
+    static const bool packed = [] { const char* e = getenv("FS_SORT_PACKED"); return e ? atoi(e) != 0 : true; }();
+#define FS_LAUNCH_INIT32(KG, GBV, PP, POS, VEL, GC)                                                                      \
+    hipLaunchKernelGGL((k_bitonic_local32<KG, GBV>), dim3(tiles), dim3(LT<GBV>::THREADS), 0, st, pairs, n, init_stages,   \
+                       dirty, PP, POS, VEL, GC)
+#define FS_LAUNCH_INIT_WIDE(KG, GBV, PP, POS, VEL, GC)                                                                   \
+    hipLaunchKernelGGL((k_bitonic_local<true, KG, GBV>), dim3(tiles), dim3(LT<GBV>::THREADS), 0, st, pairs, n, init_stages, \
+                       dirty, PP, POS, VEL, GC, (const uint32_t*)dirty, FS_TILE_WIDE, 0u)
+    if (keygen) {
+        if (packed) {
+            if (gb == 3) { FS_LAUNCH_INIT32(1, 3, *keygen, pos, vel, gap_counter); FS_LAUNCH_INIT_WIDE(1, 3, *keygen, pos, vel, gap_counter); }
+            else { FS_LAUNCH_INIT32(1, 4, *keygen, pos, vel, gap_counter); FS_LAUNCH_INIT_WIDE(1, 4, *keygen, pos, vel, gap_counter); }
+            ++launches;
+        } else if (gb == 3) FS_LAUNCH_INIT(1, 3, *keygen, pos, vel, gap_counter);
+        else FS_LAUNCH_INIT(1, 4, *keygen, pos, vel, gap_counter);
+    }
     else if (keygen3d) {
         static_assert(sizeof(KeyGen3) <= sizeof(StepParams), "KeyGen3 rides in the StepParams argument");
         memcpy(&P0, keygen3d, sizeof(KeyGen3));
-        if (gb == 3) FS_LAUNCH_INIT(2, 3, P0, (const float2*)pos4, (const float2*)vel4, gap_counter);
+        if (packed) {
+            if (gb == 3) { FS_LAUNCH_INIT32(2, 3, P0, (const float2*)pos4, (const float2*)vel4, gap_counter); FS_LAUNCH_INIT_WIDE(2, 3, P0, (const float2*)pos4, (const float2*)vel4, gap_counter); }
+            else { FS_LAUNCH_INIT32(2, 4, P0, (const float2*)pos4, (const float2*)vel4, gap_counter); FS_LAUNCH_INIT_WIDE(2, 4, P0, (const float2*)pos4, (const float2*)vel4, gap_counter); }
+            ++launches;
+        } else if (gb == 3) FS_LAUNCH_INIT(2, 3, P0, (const float2*)pos4, (const float2*)vel4, gap_counter);
         else FS_LAUNCH_INIT(2, 4, P0, (const float2*)pos4, (const float2*)vel4, gap_counter);
         memset(&P0, 0, sizeof P0);
     }
+#undef FS_LAUNCH_INIT32
+#undef FS_LAUNCH_INIT_WIDE
     else if (gb == 3) FS_LAUNCH_INIT(0, 3, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
     else FS_LAUNCH_INIT(0, 4, P0, (const float2*)nullptr, (const float2*)nullptr, (uint32_t*)nullptr);
 #undef FS_LAUNCH_INIT

@@ -369,48 +369,77 @@ __device__ __forceinline__ Terms3 pair3(const Params3& P, float4 me, float4 mv, 
 #ifndef FS3_FORCE_WAVES
 #define FS3_FORCE_WAVES 6   // measured (8 M, steps 10-110, after the safe-operand classification): 4: 2.265, 5: 2.232, 6: 2.215 ms
 #endif
-#define TILE3_PAD 64u
-#define TILE3_ROW (TILE3 + TILE3_PAD)
 
-// Mask sweep of one staged z-plane (see kernels_step.hip force_sweep_masks).  A 3D row of three cells holds
-// ~24 candidates at rest (8 particles per cell) and passes 32 as soon as the column compresses, so the pass
-// masks are 64 bits here: v_cmp + two v_addc_co per candidate shift `!(r2 > h^2)` into a register pair,
-// then every lane walks its set bits row 0, 1, 2, ascending — the oracle's visiting order.
-// `self_plane`: the lane's own particle sits in row 1 of the middle plane and is skipped (k != i).
-__device__ __forceinline__ void shift_in_not_greater64(uint32_t& lo, uint32_t& hi, float r2, float lim) {
-    asm("v_cmp_nlt_f32 vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-        : "+v"(lo), "+v"(hi) : "v"(r2), "s"(lim) : "vcc");
+// ---- tolerance mode (fs3_create_ex math_mode = FS_MATH_TOLERANCE): the pressure and viscosity terms of one in-radius
+// neighbour merged algebraically, as kernels_step.hip force_accum_tol does in 2D: one v_rsq_f32, fused multiply-adds,
+// 1/rho_j from the density pass (vel_s.w), ~32 issue slots per pair instead of ~95.  Coincident particles keep the
+// oracle's xorshift direction.
+struct Tol3 { float cP, c3, c2, hh, kp0; };
+__device__ __forceinline__ Tol3 tol3_consts(const Params3& P) {
+    Tol3 C;
+    const float h = P.h;
+    C.cP = -0.5f * P.spiky;
+    C.c3 = -1.0f / (2.0f * h * h * h);
+    C.c2 = 1.0f / (h * h);
+    C.hh = 0.5f * h;
+    C.kp0 = -P.pressure_k * P.rest_density;           // pressure_j = fma(k, rho_j, kp0)
+    return C;
+}
+__device__ __forceinline__ void accum3_tol(const Params3& P, const Tol3& C, float4 me, float4 mv, float pressure, float4 q,
+                                           float4 nv, Acc3& A) {
+    const float ox = q.x - me.x, oy = q.y - me.y, oz = q.z - me.z;
+    const float r2 = __builtin_fmaf(ox, ox, __builtin_fmaf(oy, oy, oz * oz));
+    float dx = ox, dy = oy, dz = oz, inv, dst;
+    if (r2 == 0.0f) {                                                   // rare: the PRNG direction
+        const float rx = rand_f32(&A.seed), ry = rand_f32(&A.seed), rz = rand_f32(&A.seed);
+        const float il = __builtin_amdgcn_rsqf(__builtin_fmaf(rx, rx, __builtin_fmaf(ry, ry, rz * rz)));
+        dx = rx * il; dy = ry * il; dz = rz * il;
+        dst = 0.0f; inv = 1.0f;
+    } else {
+        inv = __builtin_amdgcn_rsqf(r2);
+        dst = r2 * inv;
+    }
+    const float yrho = fabsf(nv.w);                                     // 1 / rho_j
+    const float pj = __builtin_fmaf(P.pressure_k, q.w, C.kp0);
+    const float w = fmaxf(P.h - dst, 0.0f);
+    const float coefP = (w * C.cP) * (pressure + pj) * yrho * inv;
+    float u = __builtin_fmaf(C.c3, dst, C.c2);
+    u = __builtin_fmaf(u, r2, -1.0f);
+    u = r2 == 0.0f ? 1.0f : __builtin_fmaf(C.hh, inv, u);
+    const float kvv = u * (P.visc_k * yrho);
+    A.px = __builtin_fmaf(dx, coefP, A.px); A.py = __builtin_fmaf(dy, coefP, A.py); A.pz = __builtin_fmaf(dz, coefP, A.pz);
+    A.vx = __builtin_fmaf(nv.x - mv.x, kvv, A.vx); A.vy = __builtin_fmaf(nv.y - mv.y, kvv, A.vy); A.vz = __builtin_fmaf(nv.z - mv.z, kvv, A.vz);
+}
+template <int MODE>
+__device__ __forceinline__ void pair3_accum(const Params3& P, const Tol3& C, float4 me, float4 mv, float pressure, float4 q,
+                                            float4 nv, Acc3& A) {
+    if (MODE == 2) accum3_tol(P, C, me, mv, pressure, q, nv, A);
+    else acc3_add(A, pair3(P, me, mv, pressure, q, nv, A));
 }
 
-__device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& R, const uint32_t* blo, bool self_plane,
+// Mask sweep of one staged z-plane (see kernels_step.hip force_sweep_masks): every lane walks the set bits of its three
+// 64-bit pass masks, row 0, 1, 2, ascending — the oracle's visiting order.  The masks come from k3_density
+// (Params3::handoff, `masks` != nullptr: three coalesced 8-byte loads) or from a scan of the staged plane.
+// `self_plane`: the lane's own particle sits in row 1 of the middle plane and is skipped (k != i).
+template <int MODE>
+__device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, const RowRanges& R, const uint32_t* blo, bool self_plane,
                                              uint32_t ii, float4 me, float4 mv, float pressure,
-                                             const float4* __restrict__ vel_s, const float4* s_flat, Acc3& A) {
-    typedef unsigned long long u64m;
+                                             const float4* __restrict__ vel_s, const float4* s_flat,
+                                             const u64m* __restrict__ masks, Acc3& A) {
     u64m m[3];
     uint32_t la[3];
-    const float lim = P.h2;
+    if (masks) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const uint32_t len = R.hi[r] - R.lo[r];                           // <= 64 (caller)
-        la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
-        const float4* base = s_flat + la[r];
-        uint32_t mlo = 0, mhi = 0, t = 0;
-        for (; __any(t < len); t += 4u) {                                 // t is wave-uniform
-            const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
-            const float4 qq[4] = {q0, q1, q2, q3};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
-                shift_in_not_greater64(mlo, mhi, ox * ox + oy * oy + oz * oz, lim);
-            }
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t len = R.hi[r] - R.lo[r];
+            la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
+            m[r] = masks[(size_t)r * P.n + ii];                            // all-zero for lanes past the end (never written: masked below)
+            m[r] &= len ? ~0ull << (64u - len) : 0ull;
         }
-        // candidate t sits at bit (trips - 1 - t): left-align, keep the lane's own len candidates
-        u64m mask = ((u64m)mhi << 32) | mlo;
-        mask = t ? mask << (64u - t) : 0ull;
-        mask &= len ? ~0ull << (64u - len) : 0ull;
-        if (r == 1 && self_plane && ii - R.lo[1] < len) mask &= ~(0x8000000000000000ull >> (ii - R.lo[1]));
-        m[r] = mask;
+    } else {
+        scan3_plane(P, R, blo, me, s_flat, m, la);
     }
+    if (self_plane && ii - R.lo[1] < R.hi[1] - R.lo[1]) m[1] &= ~(0x8000000000000000ull >> (ii - R.lo[1]));
     uint32_t la0 = la[0] << 4, la1 = la[1] << 4, la2 = la[2] << 4, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
     asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));   // keep them registers
     // Software-pipelined by one neighbour (as in the 2D kernel): the LDS read and the velocity gather of
@@ -441,7 +470,7 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& 
         const bool cur_valid = have;
         const float4 q0 = qn, v0 = vn;
         FS3_FETCH_NEXT();
-        if (cur_valid) acc3_add(A, pair3(P, me, mv, pressure, q0, v0, A));
+        if (cur_valid) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A);
     }
 #undef FS3_FETCH_NEXT
 }
@@ -454,8 +483,8 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const RowRanges& 
 __device__ __forceinline__ void shift_in_not_greater32(uint32_t& mask, float r2, float lim) {
     asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
 }
-template <bool STAGED>
-__device__ __forceinline__ void sweep3_chunks(const Params3& P, const RowRanges& R, const uint32_t* blo, bool self_plane,
+template <bool STAGED, int MODE>
+__device__ __forceinline__ void sweep3_chunks(const Params3& P, const Tol3& C, const RowRanges& R, const uint32_t* blo, bool self_plane,
                                               uint32_t ii, float4 me, float4 mv, float pressure,
                                               const float4* __restrict__ pred, const float4* __restrict__ vel_s,
                                               const float4* s_flat, Acc3& A) {
@@ -506,7 +535,7 @@ __device__ __forceinline__ void sweep3_chunks(const Params3& P, const RowRanges&
                 const bool cur_valid = have;
                 const float4 q0 = qn, v0 = vn;
                 FS3_FETCH_NEXT1();
-                if (cur_valid) acc3_add(A, pair3(P, me, mv, pressure, q0, v0, A));
+                if (cur_valid) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A);
             }
 #undef FS3_FETCH_NEXT1
 #undef FS3_CAND
@@ -517,10 +546,11 @@ __device__ __forceinline__ void sweep3_chunks(const Params3& P, const RowRanges&
 // The 27-cell sweep runs plane by plane (z outer).  Per plane the workgroup's three row ranges are staged
 // into LDS (as in k3_density) and swept with register pass-masks (sweep3_masks); waves that hold a range
 // longer than 64, and planes whose rows do not fit the tile, take the chunked sweep.
+template <int MODE>
 __global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES, FS3_FORCE_WAVES))) void k3_force(Params3 P, const float4* __restrict__ pos_s,
                                                const float4* __restrict__ vel_s, const float4* __restrict__ pred,
                                                const uint32_t* __restrict__ cs, float4* __restrict__ pos_out,
-                                               float4* __restrict__ vel_out) {
+                                               float4* __restrict__ vel_out, const u64m* __restrict__ masks) {
     __shared__ float4 s_buf[3 * TILE3_ROW];           // the staged plane
     __shared__ uint32_t s_red[24];
     const uint32_t tid = threadIdx.x;
@@ -531,6 +561,7 @@ __global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WA
     const float4 mv = vel_s[ii];
     const float mrho = me.w;
     const float pressure = P.pressure_k * (mrho - P.rest_density);
+    const Tol3 C = tol3_consts(P);                      // dead code unless MODE == 2
     Acc3 A;
     A.px = A.py = A.pz = A.vx = A.vy = A.vz = 0.0f;
     A.seed = ii * 12u + P.frame * 69u;
@@ -552,16 +583,17 @@ __global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WA
         }
         uint32_t blo[3], bhi[3];
         const bool fit = block_tile_bounds(R, s_red, blo, bhi, TILE3);
-        const bool long_row = R.hi[0] - R.lo[0] > 64u || R.hi[1] - R.lo[1] > 64u || R.hi[2] - R.lo[2] > 64u;
         if (fit) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
                 for (uint32_t j = tid; j < bhi[r] - blo[r]; j += B3) s_buf[r * TILE3_ROW + j] = pred[blo[r] + j];
             __syncthreads();
-            if (!__any(long_row)) sweep3_masks(P, R, blo, plane == 1, ii, me, mv, pressure, vel_s, s_buf, A);
-            else sweep3_chunks<true>(P, R, blo, plane == 1, ii, me, mv, pressure, pred, vel_s, s_buf, A);
+            if (plane_masked(R, fit))     // the same predicate as k3_density: its masks exist exactly for these planes
+                sweep3_masks<MODE>(P, C, R, blo, plane == 1, ii, me, mv, pressure, vel_s, s_buf,
+                                   masks ? masks + (size_t)plane * 3u * P.n : nullptr, A);
+            else sweep3_chunks<true, MODE>(P, C, R, blo, plane == 1, ii, me, mv, pressure, pred, vel_s, s_buf, A);
         } else {
-            sweep3_chunks<false>(P, R, blo, plane == 1, ii, me, mv, pressure, pred, vel_s, s_buf, A);
+            sweep3_chunks<false, MODE>(P, C, R, blo, plane == 1, ii, me, mv, pressure, pred, vel_s, s_buf, A);
         }
         __syncthreads();     // the next plane reuses s_buf / s_red
     }
@@ -652,6 +684,8 @@ struct fs_sim3 {
     Dev3<float4> pos, vel, pos_s, vel_s, pred;
     Dev3<uint32_t> key, cs, counter, dirty;
     Dev3<fsd::u64> pairs;
+    Dev3<fsd::u64> masks;        // 9 x n pass masks of the 27-cell sweep, k3_density -> k3_force (Params3::handoff)
+    bool handoff = true;
     Dev3<unsigned char> work;
     Dev3<fs3_particle> aos;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -666,7 +700,7 @@ struct fs_sim3 {
     void release() {
         sortp.release();
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); key.release(); cs.release();
-        counter.release(); dirty.release(); pairs.release(); work.release(); aos.release();
+        counter.release(); dirty.release(); pairs.release(); masks.release(); work.release(); aos.release();
         for (auto& e : ev) (void)hipEventDestroy(e);
         if (t0) (void)hipEventDestroy(t0);
         if (t1) (void)hipEventDestroy(t1);
@@ -713,6 +747,8 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     P.div_h2 = s->div_h2;
     // the classification bounds the pressure numerators by (1 + 2^-22) h spiky 2^39 <= 2^60 (fs_device.h)
     P.share_div = (s->share_div && h * P.spiky <= FS_HSPIKY_HI) ? 1 : 0;
+    P.handoff = s->handoff ? 1 : 0;
+    const bool tol = s->math_mode == FS_MATH_TOLERANCE;
     hipStream_t st = s->stream;
     hipEvent_t* ev = nullptr;
     if (s->profile) {
@@ -723,19 +759,30 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     const dim3 grid((s->n + B3 - 1) / B3), block(B3);
     H3(s->sortp.throttle());                           // at most SortPolicy::FLIGHT steps ahead of the device
     if (ev) H3(hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL(k3_predict_key, grid, block, 0, st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
+    // predict + key are fused into the first sort kernel (k_bitonic_local<true, 2, *>), as in 2D: no separate launch,
+    // the unsorted pairs never touch HBM.  FS3_SEPARATE_KEYGEN=1 keeps the round-2 kernel (A/B measurements).
+    static const bool separate_keygen = getenv("FS3_SEPARATE_KEYGEN") != nullptr;
+    if (separate_keygen) hipLaunchKernelGGL(k3_predict_key, grid, block, 0, st, P, s->pos.p, s->vel.p, s->pairs.p, s->counter.p);
     if (ev) H3(hipEventRecord(ev[1], st));
     fsd::SortPlan plan;
     if (!s->sortp.plan(s->n, &plan)) return fail3(FS_ERR_DEVICE, "sort: the stand-by kernel's grid barrier timed out");
-    launch_bitonic_sort(st, s->pairs.p, s->n, s->dirty.p, nullptr, nullptr, nullptr, nullptr, &plan);
+    if (separate_keygen) {
+        launch_bitonic_sort(st, s->pairs.p, s->n, s->dirty.p, nullptr, nullptr, nullptr, nullptr, &plan);
+    } else {
+        const fsd::KeyGen3 kg{P.dt, P.h, P.bx, P.by, P.bz, P.gw, P.gh};
+        launch_bitonic_sort(st, s->pairs.p, s->n, s->dirty.p, nullptr, nullptr, nullptr, s->counter.p, &plan, &kg, s->pos.p, s->vel.p);
+    }
     if (ev) H3(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k3_reorder, grid, block, 0, st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p,
                        s->pred.p, s->key.p, s->cs.p, (GapEntry*)s->work.p, s->counter.p, s->work_cap);
     launch_fill_gaps(st, s->cs.p, s->work.p, s->counter.p, s->work_cap);
     if (ev) H3(hipEventRecord(ev[3], st));
-    hipLaunchKernelGGL(k3_density, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p);
+    const fsd::u64* fm = s->handoff ? s->masks.p : nullptr;
+    if (tol) hipLaunchKernelGGL(k3_density<2>, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p);
+    else hipLaunchKernelGGL(k3_density<0>, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p);
     if (ev) H3(hipEventRecord(ev[4], st));
-    hipLaunchKernelGGL(k3_force, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p);
+    if (tol) hipLaunchKernelGGL(k3_force<2>, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm);
+    else hipLaunchKernelGGL(k3_force<0>, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm);
     if (ev) { H3(hipEventRecord(ev[5], st)); s->pending += 1; }
     H3(s->sortp.step_enqueued(st));
     H3(hipGetLastError());
@@ -787,6 +834,8 @@ fs_status fs3_create_ex(const fs3_settings* st, int device, fs_vec3 off, int mat
     T3(s->key.alloc(n)); T3(s->pairs.alloc(n)); T3(s->cs.alloc((size_t)s->ncell + 1)); T3(s->counter.alloc(4));
     T3(s->dirty.alloc(fsd::sort_tile_count((uint32_t)n))); T3(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
     T3(s->aos.alloc(n));
+    s->handoff = !(getenv("FS3_HANDOFF") && atoi(getenv("FS3_HANDOFF")) == 0);
+    if (s->handoff) T3(s->masks.alloc(9 * n));
     T3(hipEventCreate(&s->t0)); T3(hipEventCreate(&s->t1));
     T3(hipMemsetAsync(s->cs.p, 0, s->cs.n * 4, s->stream));
     T3(hipMemsetAsync(s->counter.p, 0, 16, s->stream));

@@ -1,6 +1,8 @@
 """3D extension (27-cell path).  The reference is 2D only: the oracle here is this repo's own
 statement (oracle/sph_oracle3d.cpp) — parity with a reference is undefined;
 what is pinned: analytic kernel constants / interior lattice density, and HIP == oracle bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -171,3 +173,90 @@ def test_3d_8m_full_state_matches_oracle(fs, orc):
         _assert_equal3(got, ref.particles_view(), "3d 8M step 1")
     finally:
         orc.set_threads(1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,seed,pre", [(16, None, 0), (24, 7, 3), (33, 9, 10), (12, 2, 0)])
+def test_3d_tolerance_mode_within_tolerance(fs, orc, side, seed, pre):
+    """fs3_create_ex(FS_MATH_TOLERANCE): one step from an identical state against the 3D oracle — cell keys bit-exact
+    (sort and reorder are untouched), predicted positions bit-exact, density rtol 1e-5, velocity rtol 1e-5 + atol 2e-5,
+    position atol 1e-4 * h; `pre` strict steps first so the state is not a lattice."""
+    n = side ** 3
+    st, off, tick = fs.dam_break_3d(n)
+    ref = orc.OracleSim3D(st, off)
+    p = ref.particles()
+    if seed is not None:
+        rng = np.random.default_rng(seed)
+        p["position"] += rng.uniform(-0.03, 0.03, size=(n, 3)).astype(np.float32)
+        p["predicted_position"] = p["position"]
+        p["velocity"] = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        if side == 12:                                     # coincident particles: the PRNG direction is kept
+            p["position"][1:4] = p["position"][0]
+            p["predicted_position"][1:4] = p["position"][0]
+        ref.set_particles(p)
+    for _ in range(pre):
+        ref.step(tick)
+    state = ref.particles()
+    sim = fs.FluidSimulation3D(st, device=0, initial_offset=off, math_mode=fs.FS_MATH_TOLERANCE)
+    sim.upload_particles(state)
+    sim.tick(tick)
+    ref.step(tick)
+    got, want = sim.download_particles(), ref.particles()
+    assert np.array_equal(got["grid"], want["grid"]), "cell keys must stay bit-exact in tolerance mode"
+    assert np.array_equal(got["predicted_position"].view(np.uint32), want["predicted_position"].view(np.uint32))
+    h = float(st.smoothing_radius)
+    np.testing.assert_allclose(got["density"], want["density"], rtol=1e-5)
+    np.testing.assert_allclose(got["velocity"], want["velocity"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(got["position"], want["position"], rtol=0, atol=1e-4 * h)
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_3d_tolerance_mode_many_steps_stays_close(fs, orc):
+    """20 tolerance-mode steps of a 27k-particle dam break: keys identical to the oracle while no particle sits within
+    rounding distance of a cell face; rounding-level differences grow ~2.4x per step at the free surface, so
+    after 20 steps only bulk statistics are compared (1 %)."""
+    st, off, tick = fs.dam_break_3d(30 ** 3)
+    sim = fs.FluidSimulation3D(st, device=0, initial_offset=off, math_mode=fs.FS_MATH_TOLERANCE)
+    ref = orc.OracleSim3D(st, off)
+    for _ in range(20):
+        sim.tick(tick); ref.step(tick)
+    got, want = sim.download_particles(), ref.particles()
+    assert np.isfinite(got["position"]).all()
+    assert abs(float(got["density"].mean()) / float(want["density"].mean()) - 1.0) < 1e-2
+    assert abs(float(np.abs(got["velocity"]).mean()) / float(np.abs(want["velocity"]).mean()) - 1.0) < 1e-2
+    assert np.abs(got["position"]).max() <= max(st.size.x, st.size.y, st.size.z) / 2
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_3d_mask_handoff_does_not_change_a_bit(fs, tmp_path):
+    """k3_density hands its nine pass masks to k3_force (default); FS3_HANDOFF=0 makes the force pass scan the 216
+    candidates itself as in round 2, FS3_SEPARATE_KEYGEN=1 brings back the separate predict+key launch.  Same bits."""
+    import subprocess, sys, textwrap
+    prog = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import gpu_fluid_simulation_amd as fs
+        st, off, tick = fs.dam_break_3d(40 ** 3)
+        sim = fs.FluidSimulation3D(st, device=0, initial_offset=off)
+        rng = np.random.default_rng(5)
+        p = sim.download_particles()
+        p["position"] += rng.uniform(-0.03, 0.03, size=p["position"].shape).astype(np.float32)
+        p["predicted_position"] = p["position"]
+        idx = rng.choice(p.shape[0], 1500, replace=False)       # a dense cluster: rows > 64 take the chunked sweep
+        p["position"][idx] = rng.uniform(-0.2, 0.2, size=(1500, 3)).astype(np.float32)
+        p["predicted_position"] = p["position"]
+        sim.upload_particles(p)
+        for _ in range(6):
+            sim.tick(tick)
+        np.save(sys.argv[1], sim.download_particles())
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for k, env in enumerate(({}, {"FS3_HANDOFF": "0"}, {"FS3_SEPARATE_KEYGEN": "1"})):
+        out = tmp_path / f"o{k}.npy"
+        r = subprocess.run([sys.executable, "-c", prog, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8))
+    assert np.array_equal(outs[0].view(np.uint8), outs[2].view(np.uint8))

@@ -9,9 +9,10 @@ lib = sys.argv[3] if len(sys.argv) > 3 else 'default'
 if lib != 'default':
     _abi._lib = _abi.load_library(os.path.join('gpu-fluid-simulation_amd', lib))
 st, off, tick = g.dam_break_3d(200 ** 3)
-sim = g.FluidSimulation3D(st, device=0, initial_offset=off)
+mode = g.FS_MATH_TOLERANCE if os.environ.get('FS3_TOL') else g.FS_MATH_IEEE
+sim = g.FluidSimulation3D(st, device=0, initial_offset=off, math_mode=mode)
 for _ in range(warm): sim.tick(tick)
 sim.sync(); sim.profile(True); sim.profile_read(True)
 ms = sim.timed_steps(tick, steps)
 p, k = sim.profile_read(True)
-print("3d", lib, f"steps {warm}-{warm+steps}", round(ms / steps, 4), {a: round(b / steps, 4) for a, b in p.items()}, flush=True)
+print("3d", lib, "tol" if os.environ.get("FS3_TOL") else "strict", {k: v for k, v in os.environ.items() if k.startswith("FS3_")}, f"steps {warm}-{warm+steps}", round(ms / steps, 4), {a: round(b / steps, 4) for a, b in p.items()}, flush=True)
