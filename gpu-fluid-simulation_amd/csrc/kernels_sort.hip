@@ -318,8 +318,16 @@ __global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_local(u64* __restri
 // keys only: the arrangement — ties included — is bit for bit the 64-bit kernel's (tests/test_sort_gpu.py).
 // Tiles whose keys span 2^20 or more are left untouched and flagged FS_TILE_WIDE in `dirty`; the 64-bit kernel follows
 // in the stream and takes exactly those (an idle launch otherwise).
+#ifndef FS_SORT32_WAVES
+#define FS_SORT32_WAVES 0      // > 0: pin the register budget to that many waves per SIMD (A/B: tools/ab_variant.py)
+#endif
+#if FS_SORT32_WAVES > 0
+#define FS_SORT32_ATTR __attribute__((amdgpu_waves_per_eu(FS_SORT32_WAVES, FS_SORT32_WAVES)))
+#else
+#define FS_SORT32_ATTR
+#endif
 template <int KEYGEN, int GB>
-__global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_local32(u64* __restrict__ pairs, uint32_t n,
+__global__ __launch_bounds__(LT<GB>::THREADS) FS_SORT32_ATTR void k_bitonic_local32(u64* __restrict__ pairs, uint32_t n,
                                                                      uint32_t num_stages, uint32_t* __restrict__ dirty,
                                                                      StepParams P, const float2* __restrict__ pos,
                                                                      const float2* __restrict__ vel,

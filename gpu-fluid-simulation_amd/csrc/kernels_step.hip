@@ -573,15 +573,20 @@ __device__ __forceinline__ bool force_sweep_masks(const StepParams& P, const Row
         if (r == 1 && ii - R.lo[1] < len) mask &= ~(0x80000000u >> (ii - R.lo[1]));
         m[r] = mask;
     }
-    // plain registers: left as arrays the compiler turns the selects below into an indexed scratch load
-    uint32_t la0 = la[0] << 3, la1 = la[1] << 3, la2 = la[2] << 3, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
-    asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));
+    // The three masks are walked as a shift register (round 3): `cur` is the mask being consumed with its LDS / global
+    // bases, (n1, n2) wait behind it.  Empty masks are squeezed out first, so "cur == 0 -> pull n1" is all a refill ever
+    // needs, and the per-neighbour bit extraction touches ONE mask and ONE pair of bases instead of selecting among three
+    // masks and six bases.  Row order 0, 1, 2 (= the reference visiting order) is kept.  FS_WALK_SELECT: the round-2 form.
     // Software-pipelined: the LDS read and the two gathers of a later neighbour are issued before the terms of
     // neighbour k are evaluated, so a lane's own arithmetic covers their latency.  FS_PIPE_DEPTH = 1: neighbour
     // k+1 (one slot, rotated by moves); 2: neighbours k+1 and k+2 (three slots A, B, C refilled in turn, the loop
     // unrolled by three so no value is moved).
-    uint32_t m0 = m[0], m1 = m[1], m2 = m[2];
     const wave_mask me_okm = wm(me_ok);      // the lane's own "safe operand" classification (all lanes active here)
+#ifdef FS_WALK_SELECT
+    // plain registers: left as arrays the compiler turns the selects below into an indexed scratch load
+    uint32_t la0 = la[0] << 3, la1 = la[1] << 3, la2 = la[2] << 3, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
+    asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));
+    uint32_t m0 = m[0], m1 = m[1], m2 = m[2];
 #define FS_FETCH(have, qn, vn, dn)                                                                                   \
     do {                                                                                                             \
         have = (m0 | m1 | m2) != 0u;                                                                                 \
@@ -601,6 +606,26 @@ __device__ __forceinline__ bool force_sweep_masks(const StepParams& P, const Row
             dn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rho2) + off); /* {rho, 1/rho} */     \
         }                                                                                                            \
     } while (0)
+#else
+    uint32_t cur = m[0], n1 = m[1], n2 = m[2];
+    uint32_t lac = la[0] << 3, la_1 = la[1] << 3, la_2 = la[2] << 3, loc = R.lo[0] << 3, lo_1 = R.lo[1] << 3, lo_2 = R.lo[2] << 3;   // bytes
+    if (n1 == 0u) { n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0u; }
+    if (cur == 0u) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0u; }
+#define FS_FETCH(have, qn, vn, dn)                                                                                   \
+    do {                                                                                                             \
+        have = cur != 0u;                                                                                            \
+        if (have) {                                                                                                  \
+            const uint32_t t8 = (uint32_t)__builtin_clz(cur) << 3;                                                   \
+            cur ^= 0x80000000u >> (t8 >> 3);                                                                         \
+            qn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(s_flat) + (lac + t8));               \
+            /* both arrays hold 8-B elements: one 32-bit byte offset from the two SGPR bases (n <= 2^28) */          \
+            const uint32_t off = loc + t8;                                                                           \
+            vn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vel_s) + off);                       \
+            dn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rho2) + off); /* {rho, 1/rho} */     \
+            if (cur == 0u) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0u; }         \
+        }                                                                                                            \
+    } while (0)
+#endif
 #define FS_PAIR(cur_valid, q0, v0, d0)                                                                               \
     do {                                                                                                             \
         if (cur_valid && MODE == 2) {                                                                                \

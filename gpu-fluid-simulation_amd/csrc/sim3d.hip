@@ -132,6 +132,10 @@ __device__ __forceinline__ void shift_in_not_greater64(uint32_t& lo, uint32_t& h
     asm("v_cmp_nlt_f32 vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
         : "+v"(lo), "+v"(hi) : "v"(r2), "s"(lim) : "vcc");
 }
+// FS3_B96 (A/B): the scan reads 12-byte views of the staged records — ds_read_b96, 768 instead of 1 024 bytes per wave
+// instruction (only x, y, z are needed for r2); profiles/r03_rejected.md has the measurement.
+struct alignas(4) F3 { float x, y, z; };
+template <bool XYZ_ONLY = false>
 __device__ __forceinline__ void scan3_plane(const Params3& P, const RowRanges& R, const uint32_t* blo, float4 me,
                                             const float4* s_flat, u64m m[3], uint32_t la[3]) {
     const float lim = P.h2;
@@ -142,6 +146,19 @@ __device__ __forceinline__ void scan3_plane(const Params3& P, const RowRanges& R
         const float4* base = s_flat + la[r];
         uint32_t mlo = 0, mhi = 0, t = 0;
         for (; __any(t < len); t += 4u) {                                 // t is wave-uniform
+#ifdef FS3_B96
+            if (XYZ_ONLY) {
+                const F3 q0 = *reinterpret_cast<const F3*>(base + t), q1 = *reinterpret_cast<const F3*>(base + t + 1u);
+                const F3 q2 = *reinterpret_cast<const F3*>(base + t + 2u), q3 = *reinterpret_cast<const F3*>(base + t + 3u);
+                const F3 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
+                    shift_in_not_greater64(mlo, mhi, ox * ox + oy * oy + oz * oz, lim);
+                }
+                continue;
+            }
+#endif
             const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
             const float4 qq[4] = {q0, q1, q2, q3};
 #pragma unroll
@@ -176,8 +193,16 @@ __device__ __forceinline__ float dens3_tol(const Params3& P, float4 me, float4 q
 // scan the plane into masks and add the terms of the set bits (row 0, 1, 2, ascending: the oracle's order — the
 // candidates outside the radius contribute +0 there, which changes no bit of a non-negative sum); other waves loop
 // over their candidates directly.  MODE 2 (FS_MATH_TOLERANCE): FMA terms, the constant applied once.
+#ifndef FS3_DENSITY_WAVES
+#define FS3_DENSITY_WAVES 0   // > 0: pin the register budget (A/B: tools/ab_variant3d.py)
+#endif
+#if FS3_DENSITY_WAVES > 0
+#define FS3_DENSITY_ATTR __attribute__((amdgpu_waves_per_eu(FS3_DENSITY_WAVES, FS3_DENSITY_WAVES)))
+#else
+#define FS3_DENSITY_ATTR
+#endif
 template <int MODE>
-__global__ __launch_bounds__(B3) void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs,
+__global__ __launch_bounds__(B3) FS3_DENSITY_ATTR void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs,
                                                  float4* __restrict__ vel_s, u64m* __restrict__ masks) {
     __shared__ float4 s_pred[3 * TILE3_ROW];
     __shared__ uint32_t s_red[24];
@@ -211,7 +236,7 @@ __global__ __launch_bounds__(B3) void k3_density(Params3 P, float4* __restrict__
             if (plane_masked(R, fit)) {
                 u64m m[3];
                 uint32_t la[3];
-                scan3_plane(P, R, blo, me, s_pred, m, la);
+                scan3_plane<true>(P, R, blo, me, s_pred, m, la);
                 if (P.handoff && live) {
 #pragma unroll
                     for (int r = 0; r < 3; ++r) masks[(size_t)(plane * 3 + r) * P.n + i] = m[r];
@@ -367,7 +392,7 @@ __device__ __forceinline__ Terms3 pair3(const Params3& P, float4 me, float4 mv, 
 // (the general sweep, sweep3_chunks, follows the mask sweep below: it shares its helpers)
 
 #ifndef FS3_FORCE_WAVES
-#define FS3_FORCE_WAVES 6   // measured (8 M, steps 10-110, after the safe-operand classification): 4: 2.265, 5: 2.232, 6: 2.215 ms
+#define FS3_FORCE_WAVES 7   // round 2 (own scan): 4: 2.265, 5: 2.232, 6: 2.215 ms.  Round 3 (masks handed over by k3_density), steps 10-50 / 50-110: 5: 1.42 / 2.48, 6: 1.45 / 2.45, 7: 1.38 / 2.38 ms
 #endif
 
 // ---- tolerance mode (fs3_create_ex math_mode = FS_MATH_TOLERANCE): the pressure and viscosity terms of one in-radius
@@ -440,29 +465,28 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, co
         scan3_plane(P, R, blo, me, s_flat, m, la);
     }
     if (self_plane && ii - R.lo[1] < R.hi[1] - R.lo[1]) m[1] &= ~(0x8000000000000000ull >> (ii - R.lo[1]));
-    uint32_t la0 = la[0] << 4, la1 = la[1] << 4, la2 = la[2] << 4, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
-    asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));   // keep them registers
+    // The three masks are walked as a shift register (round 3): `cur` is the mask being consumed with its LDS / global
+    // bases, (n1, n2) wait behind it.  Empty masks are squeezed out first, so "cur == 0 -> pull n1" is all a refill ever
+    // needs and the per-neighbour bit extraction touches ONE 64-bit mask and ONE pair of bases (the round-2 form selected
+    // among three masks and six bases for every neighbour: ~40 instructions, now ~23).  Row order 0, 1, 2 is kept.
+    u64m cur = m[0], n1 = m[1], n2 = m[2];
+    uint32_t lac = la[0] << 4, la_1 = la[1] << 4, la_2 = la[2] << 4, loc = R.lo[0], lo_1 = R.lo[1], lo_2 = R.lo[2];   // la* in bytes
+    if (n1 == 0ull) { n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }
+    if (cur == 0ull) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }
     // Software-pipelined by one neighbour (as in the 2D kernel): the LDS read and the velocity gather of
     // neighbour k+1 are issued before the terms of neighbour k are evaluated.
     float4 qn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = qn;
     bool have = false;
-    u64m m0 = m[0], m1 = m[1], m2 = m[2];
 #define FS3_FETCH_NEXT()                                                                                             \
     do {                                                                                                             \
-        have = (m0 | m1 | m2) != 0ull;                                                                               \
+        have = cur != 0ull;                                                                                          \
         if (have) {                                                                                                  \
-            const bool s0 = m0 != 0ull, s1 = m1 != 0ull;                                                             \
-            const u64m cur = s0 ? m0 : s1 ? m1 : m2;                                                                 \
             const uint32_t t = (uint32_t)__builtin_clzll(cur);                                                       \
-            const u64m bit = 0x8000000000000000ull >> t;                                                             \
-            m0 ^= s0 ? bit : 0ull;                                                                                   \
-            m1 ^= (!s0 && s1) ? bit : 0ull;                                                                          \
-            m2 ^= (!s0 && !s1) ? bit : 0ull;                                                                         \
-            qn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_flat) +                            \
-                                                  ((s0 ? la0 : s1 ? la1 : la2) + (t << 4))); /* la* in bytes */      \
+            cur ^= 0x8000000000000000ull >> t;                                                                       \
+            qn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_flat) + (lac + (t << 4)));         \
             /* 32-bit byte offset from the SGPR base (n <= 2^28) instead of 64-bit address arithmetic */             \
-            vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) +                             \
-                                                  (((s0 ? lo0 : s1 ? lo1 : lo2) + t) << 4));                         \
+            vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + ((loc + t) << 4));          \
+            if (cur == 0ull) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }     \
         }                                                                                                            \
     } while (0)
     FS3_FETCH_NEXT();
@@ -547,12 +571,11 @@ __device__ __forceinline__ void sweep3_chunks(const Params3& P, const Tol3& C, c
 // into LDS (as in k3_density) and swept with register pass-masks (sweep3_masks); waves that hold a range
 // longer than 64, and planes whose rows do not fit the tile, take the chunked sweep.
 template <int MODE>
-__global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES, FS3_FORCE_WAVES))) void k3_force(Params3 P, const float4* __restrict__ pos_s,
-                                               const float4* __restrict__ vel_s, const float4* __restrict__ pred,
-                                               const uint32_t* __restrict__ cs, float4* __restrict__ pos_out,
-                                               float4* __restrict__ vel_out, const u64m* __restrict__ masks) {
-    __shared__ float4 s_buf[3 * TILE3_ROW];           // the staged plane
-    __shared__ uint32_t s_red[24];
+__device__ __forceinline__ void force3_body(const Params3& P, const float4* __restrict__ pos_s,
+                                            const float4* __restrict__ vel_s, const float4* __restrict__ pred,
+                                            const uint32_t* __restrict__ cs, float4* __restrict__ pos_out,
+                                            float4* __restrict__ vel_out, const u64m* __restrict__ masks, float4* s_buf,
+                                            uint32_t* s_red) {
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * B3 + tid;
     const bool live = i < P.n;
@@ -614,6 +637,30 @@ __global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WA
     p.w = 0.0f; v.w = 0.0f;
     pos_out[i] = p;
     vel_out[i] = v;
+}
+// One kernel per math mode: the register budget that measured best differs (strict: 7 waves per SIMD, tolerance: 6).
+#ifndef FS3_FORCE_WAVES_TOL
+#define FS3_FORCE_WAVES_TOL 6
+#endif
+template <int MODE> __global__ void k3_force(Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s,
+                                             const float4* __restrict__ pred, const uint32_t* __restrict__ cs,
+                                             float4* __restrict__ pos_out, float4* __restrict__ vel_out,
+                                             const u64m* __restrict__ masks);
+template <>
+__global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES, FS3_FORCE_WAVES))) void k3_force<0>(
+    Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
+    const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks) {
+    __shared__ float4 s_buf[3 * TILE3_ROW];           // the staged plane
+    __shared__ uint32_t s_red[24];
+    force3_body<0>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, s_buf, s_red);
+}
+template <>
+__global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES_TOL, FS3_FORCE_WAVES_TOL))) void k3_force<2>(
+    Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
+    const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks) {
+    __shared__ float4 s_buf[3 * TILE3_ROW];
+    __shared__ uint32_t s_red[24];
+    force3_body<2>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, s_buf, s_red);
 }
 
 __global__ __launch_bounds__(B3) void k3_export(uint32_t n, const float4* __restrict__ pos, const float4* __restrict__ pred,
