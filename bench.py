@@ -39,16 +39,16 @@ WORKLOADS = {
     "dam_break_2d_64M": 1 << 26,
     "dam_break_3d_8M": 200 ** 3,
 }
-ALG_BYTES_3D = {"predict_key": 40, "sort": 12, "reorder": 72 + 4, "density": 20, "force": 68}   # 216 B (3D keeps predict+key as its own kernel)
+ALG_BYTES_3D = {"sort": 40 + 12, "reorder": 72 + 4, "density": 20, "force": 68}   # 216 B; predict + key (40 B) run inside the first sort kernel, as in 2D
 ALG_TOTAL_3D = 216
 
 # which kernel carries a pass: EXACT names as rocprofv3 prints them (profiles/counters_latest.json keys), first match wins
 PASS_KERNEL = {"force": ["fsd::k_force<0, false>"], "density": ["fsd::k_density<false>"],
-               "sort": ["fsd::k_bitonic_local<true, 1, 4>", "fsd::k_bitonic_local<true, 1, 3>", "fsd::k_bitonic_local<true, true, 4>"],
-               "reorder": ["fsd::k_reorder<true>"]}
-PASS_KERNEL_3D = {"force": ["fsd::k3_force<0>", "fsd::k3_force"], "density": ["fsd::k3_density<0>", "fsd::k3_density"],
-                  "sort": ["fsd::k_bitonic_local<true, 2, 4>", "fsd::k_bitonic_local<true, false, 4>"],
-                  "reorder": ["fsd::k3_reorder"], "predict_key": ["fsd::k3_predict_key"]}
+               "sort": ["fsd::k_bitonic_local32<1, 4>", "fsd::k_bitonic_local32<1, 3>"], "reorder": ["fsd::k_reorder<true>"]}
+PASS_KERNEL_3D = {"force": ["fsd::k3_force<0>"], "density": ["fsd::k3_density<0>"],
+                  "sort": ["fsd::k_bitonic_local32<2, 4>"], "reorder": ["fsd::k3_reorder"]}
+PASS_KERNEL_3D_TOL = {"force": ["fsd::k3_force<2>"], "density": ["fsd::k3_density<2>"],
+                      "sort": ["fsd::k_bitonic_local32<2, 4>"], "reorder": ["fsd::k3_reorder"]}
 
 
 def usable_cores():
@@ -161,14 +161,14 @@ def load_json(name):
         return None
 
 
-def bound_from_evidence(dom, hbm_frac_of_copy, counters, is3d):
+def bound_from_evidence(dom, hbm_frac_of_copy, counters, is3d, names=None):
     """What limits the dominant kernel, from the committed rocprofv3 counter summary (profiles/counters_latest.json,
     produced by tools/pmc_counters.py): HBM when the algorithmic rate is near the measured copy rate, else the VALU
     issue slots when they are mostly busy, else latency (waves parked on memory / LDS)."""
     if counters is None:
         return "hbm" if hbm_frac_of_copy >= 0.6 else "unknown (no counter summary committed)", None
     row = None
-    for name in (PASS_KERNEL_3D if is3d else PASS_KERNEL).get(dom, [dom]):     # exact kernel names only (no substring match)
+    for name in (names or (PASS_KERNEL_3D if is3d else PASS_KERNEL)).get(dom, [dom]):     # exact kernel names only (no substring match)
         v = counters.get("kernels", {}).get(name)
         if v is not None:
             row = dict(v, kernel=name)
@@ -384,14 +384,15 @@ def main():
         out["alt_windows"] = dict(aw, note="per-pass events on (costs ~1 %); value in M particle-steps/s")
         # the other single-GPU configs of BASELINE.json, 10 + 100 steps each
         wl = {}
-        for name in ("dam_break_2d_1M", "dam_break_2d_64M", "dam_break_3d_8M"):
+        for name in ("dam_break_2d_1M", "dam_break_2d_64M", "dam_break_3d_8M", "dam_break_3d_8M+tolerance_math"):
             if name == args.workload:
                 continue
             try:
-                m = WORKLOADS[name]
+                m = WORKLOADS[name.split("+")[0]]
                 if name.startswith("dam_break_3d"):
                     s3, o3, t3 = g.dam_break_3d(m)
-                    mk, tk, ab, at = (lambda: g.FluidSimulation3D(s3, device=local_rank, initial_offset=o3)), t3, ALG_BYTES_3D, ALG_TOTAL_3D
+                    mm3 = g.FS_MATH_TOLERANCE if name.endswith("tolerance_math") else g.FS_MATH_IEEE
+                    mk, tk, ab, at = (lambda: g.FluidSimulation3D(s3, device=local_rank, initial_offset=o3, math_mode=mm3)), t3, ALG_BYTES_3D, ALG_TOTAL_3D
                 else:
                     s2, o2, t2 = g.dam_break_2d(m)
                     mk, tk, ab, at = (lambda: g.FluidSimulation(s2, device=local_rank, initial_offset=o2)), t2, ALG_BYTES, ALG_TOTAL
@@ -401,14 +402,16 @@ def main():
                             "passes_ms": {k: v["ms"] for k, v in tab.items()},
                             "step_frac_of_hbm_peak": round(at * m / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 d3 = max(tab, key=lambda k: tab[k]["ms"])       # this workload's own dominant pass, bound from ITS counters
-                b3, c3 = bound_from_evidence(d3, tab[d3]["alg_GBps"] / HBM_COPY_GBS, counters, name.startswith("dam_break_3d"))
+                b3, c3 = bound_from_evidence(d3, tab[d3]["alg_GBps"] / HBM_COPY_GBS, counters, name.startswith("dam_break_3d"),
+                                             PASS_KERNEL_3D_TOL if name.endswith("tolerance_math") else None)
                 wl[name]["roofline"] = {"bound": b3, "kernel": d3, "achieved": tab[d3]["alg_GBps"], "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": tab[d3]["frac"], "alg_bytes_per_particle": ab[d3],
                                         "valu_issue_frac": c3.get("valu_issue_frac") if c3 else None,
                                         "counter_kernel": c3.get("kernel") if c3 else None, "traffic": None}
             except Exception as e:      # an extra must never take the headline down with it
                 wl[name] = {"error": str(e)}
-        out["alt_workloads"] = dict(wl, note="10 warm-up + 100 timed steps each, strict mode, one GPU; 3D has no reference counterpart")
+        out["alt_workloads"] = dict(wl, note="10 warm-up + 100 timed steps each, strict mode unless named otherwise (+tolerance_math = fs3_create_ex "
+                                            "FS_MATH_TOLERANCE: rtol 1e-5 per step vs the 3D oracle, keys bit-exact), one GPU; 3D has no reference counterpart")
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)

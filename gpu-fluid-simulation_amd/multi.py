@@ -265,6 +265,7 @@ class HipSlabEngine:
         base = self._reb.data_ptr() if torch_cuda else self._reb.device_ptr
         self.sim.rebalance_stats(C.c_void_p(base + 4 * gw), C.c_void_p(base), gw)
         if torch_cuda:
+            self.sim.sync()                        # produced on the simulation's stream, which need not be torch's current one
             t.dist.all_reduce(self._reb[:gw], op=t.dist.ReduceOp.SUM)
             t.dist.all_reduce(self._reb[gw:], op=t.dist.ReduceOp.MAX)
             host = self._reb.cpu().numpy().view(np.uint32)
@@ -272,8 +273,10 @@ class HipSlabEngine:
             lib = t.lib
             g._check(lib, lib.fs_comm_allreduce(self.sim._h, t.comm, C.c_void_p(base), gw, 0, 0))              # u32, SUM
             g._check(lib, lib.fs_comm_allreduce(self.sim._h, t.comm, C.c_void_p(base + 4 * gw), 4, 0, 1))       # u32, MAX
+            self.sim.sync()                        # the ONE host synchronisation of a re-balancing step
             host = self._reb.read()
         else:
+            self.sim.sync()
             host = self._reb.read()
             th, ts = t.torch.from_numpy(host[:gw].astype(np.int64)), t.torch.from_numpy(host[gw:].astype(np.int64))
             t.dist.all_reduce(th, op=t.dist.ReduceOp.SUM)

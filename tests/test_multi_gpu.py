@@ -399,3 +399,96 @@ def test_native_rccl_self_exchange_through_the_c_abi(fs, tmp_path):
     out = subprocess.run([sys.executable, str(script), ROOT], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "native rccl self-exchange ok" in out.stdout
+
+
+def _one_slab(fs, n, own_lo_frac, own_hi_frac, recv, seed=3, vel=3.0):
+    """A slab in the middle of the domain with both neighbours present: returns (sim, settings, tick, owned records)."""
+    from gpu_fluid_simulation_amd import multi
+    st, off, tick = fs.dam_break_2d(n)
+    lat = fs.reference_lattice(st, off)
+    rng = np.random.default_rng(seed)
+    lat["position"] += rng.uniform(-0.04, 0.04, size=lat["position"].shape).astype(np.float32)
+    lat["predicted_position"] = lat["position"]
+    lat["velocity"] = rng.uniform(-vel, vel, size=lat["velocity"].shape).astype(np.float32)
+    cols = multi.global_columns(lat["position"][:, 0], st.size.x, st.smoothing_radius)
+    occ = np.nonzero(np.bincount(cols))[0]
+    lo = int(occ[0] + own_lo_frac * (occ[-1] - occ[0])); hi = int(occ[0] + own_hi_frac * (occ[-1] - occ[0]))
+    own = lat[(cols >= lo) & (cols < hi)]
+    gw = int(np.ceil(np.float32(st.size.x) / np.float32(st.smoothing_radius))) + 2
+    cap = own.shape[0] + 2 * recv + 4096
+    sim = fs.SlabSimulation(st, lo, hi, True, True, cap, recv, max_cols=gw, device=0)
+    sim.upload_owned(own)
+    return sim, st, tick, own, (lo, hi)
+
+
+def _read_message(fs, buf, message_bytes):
+    raw = buf.read()
+    hdr = raw[:16].view(np.uint32)
+    rec = raw[16:].view(np.float32).reshape(-1, 4)
+    return int(hdr[0]), int(hdr[1]), rec
+
+
+def test_pack_messages_are_in_slot_order_and_deterministic(fs):
+    """k_slab_pack + k_slab_msg: the records each neighbour gets are the flagged particles in SLOT order (the look-back
+    offsets make the compaction deterministic), identical from run to run, and exactly the particles whose predicted
+    column lies in the 2-column band at the slab edge."""
+    from gpu_fluid_simulation_amd import multi
+    outs = []
+    for _ in range(2):
+        sim, st, tick, own, (lo, hi) = _one_slab(fs, 65536, 0.30, 0.55, recv=8192)
+        sl = fs.ResizableBuffer("sl", np.uint8, sim.message_bytes); sr = fs.ResizableBuffer("sr", np.uint8, sim.message_bytes)
+        sim.pack(tick, C.c_void_p(sl.device_ptr), C.c_void_p(sr.device_ptr)); sim.sync()
+        cl, ol, rl = _read_message(fs, sl, sim.message_bytes)
+        cr, orr, rr = _read_message(fs, sr, sim.message_bytes)
+        assert ol == 0 and orr == 0 and cl > 0 and cr > 0
+        outs.append((rl[:cl].copy(), rr[:cr].copy()))
+        # expected: the uploaded (slot-ordered) records whose predicted column is within 2 of the edge
+        dt = np.float32(tick.delta)
+        pred_x = own["position"][:, 0] + own["velocity"][:, 0] * dt
+        bs = np.float32(st.size.x) * np.float32(0.5)
+        pred_x = np.where(np.abs(pred_x) > bs, bs * np.sign(pred_x), pred_x).astype(np.float32)
+        pc = multi.global_columns(pred_x, st.size.x, st.smoothing_radius)
+        want_l = own[pc < lo + 2]; want_r = own[pc + 2 >= hi]
+        assert cl == want_l.shape[0] and cr == want_r.shape[0]
+        assert np.array_equal(rl[:cl, :2].view(np.uint32), want_l["position"].view(np.uint32))
+        assert np.array_equal(rr[:cr, 2:].view(np.uint32), want_r["velocity"].view(np.uint32))
+        sim.close()
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+
+
+def test_message_overflow_is_flagged_in_header_and_counter(fs):
+    """More records than a message holds: count == capacity, header overflow flag set, fs_slab_counters.overflow != 0."""
+    sim, st, tick, own, _ = _one_slab(fs, 65536, 0.30, 0.55, recv=64)
+    sl = fs.ResizableBuffer("sl", np.uint8, sim.message_bytes); sr = fs.ResizableBuffer("sr", np.uint8, sim.message_bytes)
+    sim.pack(tick, C.c_void_p(sl.device_ptr), C.c_void_p(sr.device_ptr)); sim.sync()
+    cl, ol, _ = _read_message(fs, sl, sim.message_bytes)
+    cr, orr, _ = _read_message(fs, sr, sim.message_bytes)
+    assert (cl, ol) == (64, 1) and (cr, orr) == (64, 1)
+    empty = fs.ResizableBuffer("e", np.uint8, sim.message_bytes)      # zero header: no records
+    sim.step(C.c_void_p(empty.device_ptr), C.c_void_p(empty.device_ptr)); sim.sync()
+    assert sim.counters()["overflow"] != 0
+    sim.close()
+
+
+def test_rebalance_stats_on_device_equal_the_blocking_reads(fs):
+    """fs_slab_rebalance_stats leaves {lost, overflow, far_halo, max-speed bits} and the column histogram in device
+    buffers: same numbers as fs_slab_counters_read / fs_slab_max_speed / fs_slab_column_histogram."""
+    sim, st, tick, own, (lo, hi) = _one_slab(fs, 65536, 0.30, 0.55, recv=8192)
+    empty = fs.ResizableBuffer("e", np.uint8, sim.message_bytes)
+    sl = fs.ResizableBuffer("sl", np.uint8, sim.message_bytes); sr = fs.ResizableBuffer("sr", np.uint8, sim.message_bytes)
+    for _ in range(3):
+        sim.pack(tick, C.c_void_p(sl.device_ptr), C.c_void_p(sr.device_ptr))
+        sim.step(C.c_void_p(empty.device_ptr), C.c_void_p(empty.device_ptr))
+    sim.sync()
+    gw = int(np.ceil(np.float32(st.size.x) / np.float32(st.smoothing_radius))) + 2
+    buf = fs.ResizableBuffer("reb", np.uint32, gw + 4)
+    sim.rebalance_stats(C.c_void_p(buf.device_ptr + 4 * gw), C.c_void_p(buf.device_ptr), gw)
+    sim.sync()                                     # enqueued on the simulation's stream; the buffer read is not
+    got = buf.read()
+    c = sim.counters()
+    assert list(got[gw:gw + 3]) == [c["lost"], c["overflow"], c["far_halo"]]
+    assert got[gw + 3:gw + 4].view(np.float32)[0] == np.float32(sim.max_speed())
+    assert np.array_equal(got[:gw], sim.column_histogram(gw))
+    assert got[:gw].sum() > 0 and got[:lo].sum() == 0 and got[hi:gw].sum() == 0
+    sim.close()

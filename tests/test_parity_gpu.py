@@ -626,3 +626,30 @@ def test_tolerance_mode_mouse_field_and_guards(fs, orc):
     assert np.isfinite(got["velocity"]).all()
     np.testing.assert_allclose(got["velocity"][ok], want["velocity"][ok], rtol=2e-5, atol=1e-4)
     np.testing.assert_allclose(got["position"][ok], want["position"][ok], rtol=0, atol=1e-4 * 0.2 + 1e-5)
+
+
+@pytest.mark.parametrize("cells_side", [127, 128, 129, 255, 640])
+def test_counting_sort_scan_tile_boundaries(fs, orc, cells_side):
+    """k_scan_lookback scans 16 384 cells per workgroup: grids whose cell count sits just below / on / above tile
+    multiples (127^2 < 16 384 = 128^2 < 129^2, ...) must give the same cell table as the oracle's stable sort."""
+    h = 0.2
+    size = (cells_side - 2) * h - 0.01            # grid_w = grid_h = ceil(size / h) + 2 = cells_side
+    n = 20000
+    st = fs.SimulationSettings(n, 0.05, h, (size, size))
+    tick = fs.default_tick_settings(gravity=(0.0, 9.81))
+    sim = fs.FluidSimulation(st, device=0, sort_mode=fs.FS_SORT_COUNTING)
+    assert sim.grid_dims == (cells_side, cells_side)
+    ref = orc.OracleSim(st, (0.0, 0.0))
+    rng = np.random.default_rng(cells_side)
+    p = ref.particles()
+    p["position"] = rng.uniform(-size / 2, size / 2, size=(n, 2)).astype(np.float32)
+    p["predicted_position"] = p["position"]
+    ref.set_particles(p); sim.upload_particles(p)
+    for s in range(2):
+        sim.tick(tick); ref.step(tick, stable_sort=True)
+        got, want = sim.download_particles(), ref.particles()
+        assert np.array_equal(got["grid"], want["grid"]), f"step {s}: keys"
+        for f in ("position", "predicted_position", "velocity", "density"):
+            assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f"step {s}: {f}"
+        assert np.array_equal(sim.download_start_indices(), ref.start_indices()), f"step {s}: start_indices"
+    sim.close()

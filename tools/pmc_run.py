@@ -12,7 +12,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 mode = sys.argv[4] if len(sys.argv) > 4 else "strict"
 if scene == "3d":
     st, off, tick = g.dam_break_3d(200 ** 3)
-    sim = g.FluidSimulation3D(st, device=0, initial_offset=off)
+    sim = g.FluidSimulation3D(st, device=0, initial_offset=off, math_mode=g.FS_MATH_TOLERANCE if mode == "tol" else g.FS_MATH_IEEE)
 else:
     st, off, tick = g.dam_break_2d(1 << 20 if scene == "2d1m" else 1 << 24)
     kw = {}

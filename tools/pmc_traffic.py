@@ -23,8 +23,8 @@ def per_kernel(d, counter):
     return tot, cnt
 
 def pass_of(name):
-    if "bitonic" in name or "k_late_" in name or "k_cs_" in name or "csort" in name: return "sort"
-    if "k_reorder" in name or "k_fill_gaps" in name: return "reorder"
+    if "k_reorder" in name or "k_fill_gaps" in name or "k_cs_fixreorder" in name: return "reorder"
+    if "bitonic" in name or "k_late_" in name or "k_cs_" in name or "csort" in name or "k_scan_lookback" in name: return "sort"
     if "k_density" in name: return "density"
     if "k_force" in name: return "force"
     return None
