@@ -473,11 +473,16 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, co
     uint32_t lac = la[0] << 4, la_1 = la[1] << 4, la_2 = la[2] << 4, loc = R.lo[0], lo_1 = R.lo[1], lo_2 = R.lo[2];   // la* in bytes
     if (n1 == 0ull) { n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }
     if (cur == 0ull) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }
-    // Software-pipelined by one neighbour (as in the 2D kernel): the LDS read and the velocity gather of
-    // neighbour k+1 are issued before the terms of neighbour k are evaluated.
-    float4 qn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = qn;
-    bool have = false;
-#define FS3_FETCH_NEXT()                                                                                             \
+    // Software-pipelined (as in the 2D kernel): the LDS read and the velocity gather of later neighbours are issued
+    // before the terms of neighbour k are evaluated.  FS3_PIPE_DEPTH 1: neighbour k+1 in flight (one slot); 2: k+1 and
+    // k+2 (three slots refilled in turn, the loop unrolled by three so no value is moved).  With the masks handed over
+    // the kernel is latency-bound (profiles/r03_counters_3d*.md: waves parked 65 % / 79 % of their lifetime in strict /
+    // tolerance mode) — but the second neighbour in flight costs 16 more registers, and with 72 - 80 already in use
+    // (and 180 - 200 bytes of scratch in the chunked paths) that loses more than it covers.
+#ifndef FS3_PIPE_DEPTH
+#define FS3_PIPE_DEPTH 1      // depth 2 measured slower at every register budget (profiles/r03_rejected.md): 8 M, strict 1.95 -> 2.05 .. 2.37 ms
+#endif
+#define FS3_FETCH(have, qn, vn)                                                                                      \
     do {                                                                                                             \
         have = cur != 0ull;                                                                                          \
         if (have) {                                                                                                  \
@@ -489,14 +494,35 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, co
             if (cur == 0ull) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }     \
         }                                                                                                            \
     } while (0)
-    FS3_FETCH_NEXT();
+#if FS3_PIPE_DEPTH == 1
+    float4 qn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = qn;
+    bool have = false;
+    FS3_FETCH(have, qn, vn);
     while (__any(have)) {
         const bool cur_valid = have;
         const float4 q0 = qn, v0 = vn;
-        FS3_FETCH_NEXT();
+        FS3_FETCH(have, qn, vn);
         if (cur_valid) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A);
     }
-#undef FS3_FETCH_NEXT
+#else
+    float4 qA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vA = qA, qB = qA, vB = qA, qC = qA, vC = qA;
+    bool hA = false, hB = false, hC = false;
+    FS3_FETCH(hA, qA, vA);
+    FS3_FETCH(hB, qB, vB);
+    FS3_FETCH(hC, qC, vC);
+    for (;;) {       // a slot is refilled right after its neighbour's terms: two bodies later it is consumed
+        if (!__any(hA)) break;
+        { const bool cv = hA; const float4 q0 = qA, v0 = vA; if (cv) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A); }
+        FS3_FETCH(hA, qA, vA);
+        if (!__any(hB)) break;
+        { const bool cv = hB; const float4 q0 = qB, v0 = vB; if (cv) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A); }
+        FS3_FETCH(hB, qB, vB);
+        if (!__any(hC)) break;
+        { const bool cv = hC; const float4 q0 = qC, v0 = vC; if (cv) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A); }
+        FS3_FETCH(hC, qC, vC);
+    }
+#endif
+#undef FS3_FETCH
 }
 
 // General sweep of three rows (one z-plane) for waves that hold a row longer than 64 candidates, or whose
