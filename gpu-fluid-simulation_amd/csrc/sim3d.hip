@@ -107,6 +107,22 @@ __device__ __forceinline__ bool row3(const Params3& P, const uint32_t* __restric
     return *lo < *hi;
 }
 
+// The same row from the particle's KEY (round 3): cells (cx-1 .. cx+1, cy+oy, cz+oz) are the ids key + (oz gh + oy) gw - 1 .. + 2,
+// so the density and force passes need no cell coordinates (three IEEE divisions per particle in cell3) — only the stored
+// key.  Equivalent to row3 for every reachable key: cell index 0 of every row / plane is padding and always empty
+// (coordinates are floor(..) + 1 >= 1), so a row that wraps into the next row or plane reads an empty range exactly where
+// row3 says "outside the grid", and ids past the table are cut off here.
+__device__ __forceinline__ bool row3_key(const Params3& P, const uint32_t* __restrict__ cs, uint32_t key, int j,
+                                         uint32_t* lo, uint32_t* hi) {
+    const int32_t off = ((j / 3 - 1) * (int32_t)P.gh + (j % 3 - 1)) * (int32_t)P.gw - 1;      // scalar
+    const uint32_t id_lo = key + (uint32_t)off;                       // wraps for a row below the grid: >= ncell
+    if (id_lo >= P.ncell) return false;
+    const uint32_t id_hi = id_lo + 3u > P.ncell ? P.ncell : id_lo + 3u;
+    *lo = cs[id_lo];
+    *hi = cs[id_hi];
+    return *lo < *hi;
+}
+
 __device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
     const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
     const float r2 = dx * dx + dy * dy + dz * dz;
@@ -203,20 +219,20 @@ __device__ __forceinline__ float dens3_tol(const Params3& P, float4 me, float4 q
 #endif
 template <int MODE>
 __global__ __launch_bounds__(B3) FS3_DENSITY_ATTR void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs,
-                                                 float4* __restrict__ vel_s, u64m* __restrict__ masks) {
+                                                 float4* __restrict__ vel_s, u64m* __restrict__ masks,
+                                                 const uint32_t* __restrict__ key_s) {
     __shared__ float4 s_pred[3 * TILE3_ROW];
     __shared__ uint32_t s_red[24];
     const uint32_t i = blockIdx.x * B3 + threadIdx.x;
     const bool live = i < P.n;
     const float4 me = pred[live ? i : P.n - 1];
-    uint32_t cx, cy, cz;
-    cell3(P, me, &cx, &cy, &cz);
+    const uint32_t key = key_s[live ? i : P.n - 1];
     float rho = 0.0f;
     uint32_t lo9[9], hi9[9];        // all 18 cell-start lookups up front: independent loads, one latency
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         lo9[j] = 0; hi9[j] = 0;
-        if (live && !row3(P, cs, cx, cy, cz, j, &lo9[j], &hi9[j])) { lo9[j] = 0; hi9[j] = 0; }
+        if (live && !row3_key(P, cs, key, j, &lo9[j], &hi9[j])) { lo9[j] = 0; hi9[j] = 0; }
     }
 #pragma unroll 1
     for (int plane = 0; plane < 3; ++plane) {
@@ -600,8 +616,8 @@ template <int MODE>
 __device__ __forceinline__ void force3_body(const Params3& P, const float4* __restrict__ pos_s,
                                             const float4* __restrict__ vel_s, const float4* __restrict__ pred,
                                             const uint32_t* __restrict__ cs, float4* __restrict__ pos_out,
-                                            float4* __restrict__ vel_out, const u64m* __restrict__ masks, float4* s_buf,
-                                            uint32_t* s_red) {
+                                            float4* __restrict__ vel_out, const u64m* __restrict__ masks,
+                                            const uint32_t* __restrict__ key_s, float4* s_buf, uint32_t* s_red) {
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * B3 + tid;
     const bool live = i < P.n;
@@ -614,13 +630,12 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
     Acc3 A;
     A.px = A.py = A.pz = A.vx = A.vy = A.vz = 0.0f;
     A.seed = ii * 12u + P.frame * 69u;
-    uint32_t cx, cy, cz;
-    cell3(P, me, &cx, &cy, &cz);
+    const uint32_t key = key_s[ii];
     uint32_t lo9[9], hi9[9];        // all 18 cell-start lookups up front: independent loads, one latency
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         lo9[j] = 0; hi9[j] = 0;
-        if (live && !row3(P, cs, cx, cy, cz, j, &lo9[j], &hi9[j])) { lo9[j] = 0; hi9[j] = 0; }
+        if (live && !row3_key(P, cs, key, j, &lo9[j], &hi9[j])) { lo9[j] = 0; hi9[j] = 0; }
     }
 #pragma unroll 1
     for (int plane = 0; plane < 3; ++plane) {
@@ -671,22 +686,24 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
 template <int MODE> __global__ void k3_force(Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s,
                                              const float4* __restrict__ pred, const uint32_t* __restrict__ cs,
                                              float4* __restrict__ pos_out, float4* __restrict__ vel_out,
-                                             const u64m* __restrict__ masks);
+                                             const u64m* __restrict__ masks, const uint32_t* __restrict__ key_s);
 template <>
 __global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES, FS3_FORCE_WAVES))) void k3_force<0>(
     Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
-    const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks) {
+    const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks,
+    const uint32_t* __restrict__ key_s) {
     __shared__ float4 s_buf[3 * TILE3_ROW];           // the staged plane
     __shared__ uint32_t s_red[24];
-    force3_body<0>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, s_buf, s_red);
+    force3_body<0>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, s_buf, s_red);
 }
 template <>
 __global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES_TOL, FS3_FORCE_WAVES_TOL))) void k3_force<2>(
     Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
-    const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks) {
+    const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks,
+    const uint32_t* __restrict__ key_s) {
     __shared__ float4 s_buf[3 * TILE3_ROW];
     __shared__ uint32_t s_red[24];
-    force3_body<2>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, s_buf, s_red);
+    force3_body<2>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, s_buf, s_red);
 }
 
 __global__ __launch_bounds__(B3) void k3_export(uint32_t n, const float4* __restrict__ pos, const float4* __restrict__ pred,
@@ -851,11 +868,11 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     launch_fill_gaps(st, s->cs.p, s->work.p, s->counter.p, s->work_cap);
     if (ev) H3(hipEventRecord(ev[3], st));
     const fsd::u64* fm = s->handoff ? s->masks.p : nullptr;
-    if (tol) hipLaunchKernelGGL(k3_density<2>, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p);
-    else hipLaunchKernelGGL(k3_density<0>, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p);
+    if (tol) hipLaunchKernelGGL(k3_density<2>, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
+    else hipLaunchKernelGGL(k3_density<0>, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
     if (ev) H3(hipEventRecord(ev[4], st));
-    if (tol) hipLaunchKernelGGL(k3_force<2>, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm);
-    else hipLaunchKernelGGL(k3_force<0>, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm);
+    if (tol) hipLaunchKernelGGL(k3_force<2>, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm, s->key.p);
+    else hipLaunchKernelGGL(k3_force<0>, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm, s->key.p);
     if (ev) { H3(hipEventRecord(ev[5], st)); s->pending += 1; }
     H3(s->sortp.step_enqueued(st));
     H3(hipGetLastError());
