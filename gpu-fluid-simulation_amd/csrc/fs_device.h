@@ -222,6 +222,9 @@ __device__ __forceinline__ bool xcd_block(const StepParams& P, uint32_t nblocks,
 struct RowRanges { uint32_t lo[3], hi[3]; };
 
 // Block-wide [min lo, max hi) per sweep row; returns true when all three fit the tile.
+// WAVES: waves per workgroup (4 for the 256-thread kernels; 1 for the 3D density / force kernels, whose workgroup is one
+// wave so that no barrier couples waves with different neighbour counts).
+template <int WAVES = 4>
 __device__ __forceinline__ bool block_tile_bounds(const RowRanges& R, uint32_t* s_red /*[24]*/, uint32_t* blo,
                                                   uint32_t* bhi, uint32_t tile) {
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -247,7 +250,7 @@ __device__ __forceinline__ bool block_tile_bounds(const RowRanges& R, uint32_t* 
     for (int r = 0; r < 3; ++r) {
         uint32_t mn = s_red[(r * 2) * 4], mx = s_red[(r * 2 + 1) * 4];
 #pragma unroll
-        for (int k = 1; k < 4 /* waves per 256-thread workgroup */; ++k) {
+        for (int k = 1; k < WAVES; ++k) {
             const uint32_t a = s_red[(r * 2) * 4 + k], b = s_red[(r * 2 + 1) * 4 + k];
             mn = a < mn ? a : mn;
             mx = b > mx ? b : mx;

@@ -131,9 +131,22 @@ __device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
     return P.mass * kern * 1.0f;
 }
 
+// Workgroup of the density / force kernels: 256 threads.  -DB3F=64 (one wave per workgroup: no barrier couples waves with
+// different neighbour counts, each wave stages its own 10-cell rows) was measured and is SLOWER — density 0.93 -> 1.11 ms,
+// force 1.94 -> 2.14 ms at 8 M (profiles/r03_rejected.md): the kernels' waiting is not barrier skew.
+#ifndef B3F
+#define B3F 256
+#endif
+#define W3F (B3F / 64)
+#if B3F == 256
 #define TILE3 384            // staged candidates per sweep row; one z-plane (3 rows) is staged at a time
-#define TILE3_PAD 64u        // the wave-uniform scan reads up to the wave's longest row past a lane's own range
-#define TILE3_ROW (TILE3 + TILE3_PAD)
+#define TILE3_ROW (TILE3 + 64)
+#else
+#define TILE3 96             // a wave's row at rest: 10 cells x 8 particles; longer rows take the unstaged chunked sweep
+#define TILE3_ROW TILE3      // rows 0 and 1 over-read into the next row's stage, only the last row needs the slack below
+#endif
+#define TILE3_PAD 72u        // the wave-uniform scan reads up to the wave's longest row (<= 64) + 3 past a lane's own range
+#define TILE3_LDS (3 * TILE3_ROW + TILE3_PAD)
 typedef unsigned long long u64m;
 
 // ---- pass masks of one staged z-plane -----------------------------------------------------------------------
@@ -218,12 +231,12 @@ __device__ __forceinline__ float dens3_tol(const Params3& P, float4 me, float4 q
 #define FS3_DENSITY_ATTR
 #endif
 template <int MODE>
-__global__ __launch_bounds__(B3) FS3_DENSITY_ATTR void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs,
+__global__ __launch_bounds__(B3F) FS3_DENSITY_ATTR void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs,
                                                  float4* __restrict__ vel_s, u64m* __restrict__ masks,
                                                  const uint32_t* __restrict__ key_s) {
-    __shared__ float4 s_pred[3 * TILE3_ROW];
+    __shared__ float4 s_pred[TILE3_LDS];
     __shared__ uint32_t s_red[24];
-    const uint32_t i = blockIdx.x * B3 + threadIdx.x;
+    const uint32_t i = blockIdx.x * B3F + threadIdx.x;
     const bool live = i < P.n;
     const float4 me = pred[live ? i : P.n - 1];
     const uint32_t key = key_s[live ? i : P.n - 1];
@@ -243,11 +256,11 @@ __global__ __launch_bounds__(B3) FS3_DENSITY_ATTR void k3_density(Params3 P, flo
             R.hi[r] = plane == 0 ? hi9[r] : plane == 1 ? hi9[3 + r] : hi9[6 + r];
         }
         uint32_t blo[3], bhi[3];
-        const bool fit = block_tile_bounds(R, s_red, blo, bhi, TILE3);
+        const bool fit = block_tile_bounds<W3F>(R, s_red, blo, bhi, TILE3);
         if (fit) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
-                for (uint32_t j = threadIdx.x; j < bhi[r] - blo[r]; j += B3) s_pred[r * TILE3_ROW + j] = pred[blo[r] + j];
+                for (uint32_t j = threadIdx.x; j < bhi[r] - blo[r]; j += B3F) s_pred[r * TILE3_ROW + j] = pred[blo[r] + j];
             __syncthreads();
             if (plane_masked(R, fit)) {
                 u64m m[3];
@@ -619,7 +632,7 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
                                             float4* __restrict__ vel_out, const u64m* __restrict__ masks,
                                             const uint32_t* __restrict__ key_s, float4* s_buf, uint32_t* s_red) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t i = blockIdx.x * B3 + tid;
+    const uint32_t i = blockIdx.x * B3F + tid;
     const bool live = i < P.n;
     const uint32_t ii = live ? i : P.n - 1;
     const float4 me = pred[ii];
@@ -646,11 +659,11 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
             R.hi[r] = plane == 0 ? hi9[r] : plane == 1 ? hi9[3 + r] : hi9[6 + r];
         }
         uint32_t blo[3], bhi[3];
-        const bool fit = block_tile_bounds(R, s_red, blo, bhi, TILE3);
+        const bool fit = block_tile_bounds<W3F>(R, s_red, blo, bhi, TILE3);
         if (fit) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
-                for (uint32_t j = tid; j < bhi[r] - blo[r]; j += B3) s_buf[r * TILE3_ROW + j] = pred[blo[r] + j];
+                for (uint32_t j = tid; j < bhi[r] - blo[r]; j += B3F) s_buf[r * TILE3_ROW + j] = pred[blo[r] + j];
             __syncthreads();
             if (plane_masked(R, fit))     // the same predicate as k3_density: its masks exist exactly for these planes
                 sweep3_masks<MODE>(P, C, R, blo, plane == 1, ii, me, mv, pressure, vel_s, s_buf,
@@ -688,20 +701,20 @@ template <int MODE> __global__ void k3_force(Params3 P, const float4* __restrict
                                              float4* __restrict__ pos_out, float4* __restrict__ vel_out,
                                              const u64m* __restrict__ masks, const uint32_t* __restrict__ key_s);
 template <>
-__global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES, FS3_FORCE_WAVES))) void k3_force<0>(
+__global__ __launch_bounds__(B3F) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES, FS3_FORCE_WAVES))) void k3_force<0>(
     Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
     const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks,
     const uint32_t* __restrict__ key_s) {
-    __shared__ float4 s_buf[3 * TILE3_ROW];           // the staged plane
+    __shared__ float4 s_buf[TILE3_LDS];           // the staged plane
     __shared__ uint32_t s_red[24];
     force3_body<0>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, s_buf, s_red);
 }
 template <>
-__global__ __launch_bounds__(B3) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES_TOL, FS3_FORCE_WAVES_TOL))) void k3_force<2>(
+__global__ __launch_bounds__(B3F) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES_TOL, FS3_FORCE_WAVES_TOL))) void k3_force<2>(
     Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
     const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks,
     const uint32_t* __restrict__ key_s) {
-    __shared__ float4 s_buf[3 * TILE3_ROW];
+    __shared__ float4 s_buf[TILE3_LDS];
     __shared__ uint32_t s_red[24];
     force3_body<2>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, s_buf, s_red);
 }
@@ -868,11 +881,12 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     launch_fill_gaps(st, s->cs.p, s->work.p, s->counter.p, s->work_cap);
     if (ev) H3(hipEventRecord(ev[3], st));
     const fsd::u64* fm = s->handoff ? s->masks.p : nullptr;
-    if (tol) hipLaunchKernelGGL(k3_density<2>, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
-    else hipLaunchKernelGGL(k3_density<0>, grid, block, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
+    const dim3 gridf((s->n + B3F - 1) / B3F), blockf(B3F);        // density / force: one-wave workgroups
+    if (tol) hipLaunchKernelGGL(k3_density<2>, gridf, blockf, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
+    else hipLaunchKernelGGL(k3_density<0>, gridf, blockf, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
     if (ev) H3(hipEventRecord(ev[4], st));
-    if (tol) hipLaunchKernelGGL(k3_force<2>, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm, s->key.p);
-    else hipLaunchKernelGGL(k3_force<0>, grid, block, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm, s->key.p);
+    if (tol) hipLaunchKernelGGL(k3_force<2>, gridf, blockf, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm, s->key.p);
+    else hipLaunchKernelGGL(k3_force<0>, gridf, blockf, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm, s->key.p);
     if (ev) { H3(hipEventRecord(ev[5], st)); s->pending += 1; }
     H3(s->sortp.step_enqueued(st));
     H3(hipGetLastError());
