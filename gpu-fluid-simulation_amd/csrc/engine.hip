@@ -375,7 +375,12 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     s->tick += 1;                                              // src/simulation.rs:460
     host_uniform(s->settings, *t, s->tick, &s->uniform);
     s->uniform.particle_count = s->n;
-    const fsd::StepParams P = make_params(*s);
+    fsd::StepParams P = make_params(*s);
+    // reference-sort path: no sorted copy of the positions — the force pass takes its own particle's position from the
+    // previous state through the pair's source index and writes the new state into the spare buffer (swapped below)
+    static const bool pos_by_src_env = [] { const char* e = getenv("FS_POS_BY_SRC"); return e ? atoi(e) != 0 : true; }();
+    const bool pos_by_src = pos_by_src_env && s->opts.sort_mode != FS_SORT_COUNTING;
+    P.pos_by_src = pos_by_src ? 1 : 0;
     hipStream_t st = s->stream;
     const bool prof = s->profile;
     hipEvent_t* ev = nullptr;
@@ -405,16 +410,19 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
         fsd::launch_counting_reorder(st, P, s->csort.p, s->pairs.p, s->cs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
                                      (uint32_t*)nullptr, s->start_ref.p, s->safe.p, s->fdefer.p, s->counter.p + 4);
     else
-        fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p, (uint32_t*)nullptr, s->cs.p,
-                            s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, s->fdefer.p, s->counter.p + 4);
+        fsd::launch_reorder(st, P, s->pairs.p, s->pos.p, s->vel.p, pos_by_src ? (float2*)nullptr : s->pos_s.p, s->vel_s.p, s->pred.p,
+                            (uint32_t*)nullptr, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap, s->safe.p, s->fdefer.p,
+                            s->counter.p + 4);
     if (prof) FS_HIP(hipEventRecord(ev[3], st));
     // strict / ulp modes: rho2.x IS the density; the separate 4-byte copy is only written in tolerance mode (rho2 = {P, 1/rho})
     s->rho_in_rho2 = P.fast_math != 2;
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho_in_rho2 ? (float*)nullptr : s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
     if (prof) FS_HIP(hipEventRecord(ev[4], st));
-    fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, s->aos_live ? (void*)s->aos.p : nullptr, s->side, s->ev_fork, s->ev_join,
+    fsd::launch_force(st, P, pos_by_src ? s->pos.p : s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
+                      s->tex.p, pos_by_src ? s->pos_s.p : s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4,
+                      s->aos_live ? (void*)s->aos.p : nullptr, s->side, s->ev_fork, s->ev_join,
                       s->sortp.general_grid(), s->sortp.general_hint());
+    if (pos_by_src) { float2* t = s->pos.p; s->pos.p = s->pos_s.p; s->pos_s.p = t; }   // the spare buffer now holds the state
     if (s->aos_live) s->aos_tick = s->tick;
     if (prof) {
         FS_HIP(hipEventRecord(ev[5], st));

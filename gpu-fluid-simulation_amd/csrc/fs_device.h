@@ -42,6 +42,9 @@ struct StepParams {
     ConstDiv div_2h3, div_h2;  // the two constant denominators of funcs.wgsl:119 (2h^3, h^2)
     ConstDiv div_h;            // the cell size of funcs.wgsl:212-214, proven over every numerator a clamped position can give
     int32_t share_div;         // force pass: one true division per denominator + div_by_rcp (bit-identical)
+    int32_t pos_by_src;        // force pass: its `pos_s` argument is the PREVIOUS state in source order (own position =
+                               // pos_s[pairs[i].src]) and pos_out is a different buffer — the reorder pass then writes no
+                               // sorted copy of the positions (8 B / particle less in the HBM-bound k_reorder)
     // --- slab (multi-GPU) mode: the local grid is a window of global cell columns -------------
     int32_t col_origin;        // global column of local column 0 (0 on a single GPU)
     uint32_t own_lo, own_hi;   // owned window [own_lo, own_hi) in GLOBAL columns

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
     const uint32_t src = (uint32_t)pr;
     const float2 p = pos_in[src];
     const float2 v = vel_in[src];
-    pos_s[i] = p;
+    if (pos_s) pos_s[i] = p;                  // uniform; nullptr: the force pass reads pos_in[src] itself (StepParams::pos_by_src)
     vel_s[i] = v;
     const float2 pd = predict_pos(P, p, v);   // same expression as the key generation in the sort -> same bits
     pred_s[i] = pd;
@@ -721,6 +721,8 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
     const float2 me = pred[ii];
     const float2 mv = vel_s[ii];
     const float2 mrec = rho2[ii];                   // {rho, +-1/rho}; MODE 2: {pressure, 1/rho}
+    // own position at the start of the step: the sorted copy, or (pos_by_src) the previous state through the pair's source index
+    const float2 p_own = pos_s[P.pos_by_src ? (uint32_t)pairs[ii] : ii];
     const float mrho = MODE == 2 ? 0.0f : mrec.x;
     const bool me_ok = mrec.y > 0.0f;               // this particle's "safe operand" classification (fs_device.h)
     const float pressure = MODE == 2 ? mrec.x : P.pressure_k * (mrho - P.rest_density);      // funcs.wgsl:152-154
@@ -774,7 +776,7 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
 
     // integrate (compute.wgsl:93-153)
     float2 v = mv;
-    float2 p = pos_s[i];
+    float2 p = p_own;
     const float ax = A.fpx + fvx, ay = A.fpy + fvy;
     if (MODE == 2) {
         v.x = __builtin_fmaf(ax * mrec.y, P.dt, v.x);
