@@ -82,7 +82,9 @@ __global__ __launch_bounds__(B3) void k3_reorder(Params3 P, const u64* __restric
                        fabsf(v.x) <= 0x1p59f && fabsf(v.y) <= 0x1p59f && fabsf(v.z) <= 0x1p59f;
     float4 vs = v;
     vs.w = ksafe ? 1.0f : -1.0f;
-    pos_s[i] = p; vel_s[i] = vs; pred[i] = pd; key_s[i] = key;
+    // no sorted copy of the positions: k3_force takes its own particle's position from the previous state through the pair's
+    // source index and writes the new state into the spare buffer (16 B / particle less in this HBM-bound pass)
+    vel_s[i] = vs; pred[i] = pd; key_s[i] = key;
     const uint32_t kc = key < P.ncell ? key : P.ncell;
     if (i == 0) {
         fill_cells(cs, 0u, kc + 1u, 0u, work, counter, work_cap);
@@ -630,7 +632,8 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
                                             const float4* __restrict__ vel_s, const float4* __restrict__ pred,
                                             const uint32_t* __restrict__ cs, float4* __restrict__ pos_out,
                                             float4* __restrict__ vel_out, const u64m* __restrict__ masks,
-                                            const uint32_t* __restrict__ key_s, float4* s_buf, uint32_t* s_red) {
+                                            const uint32_t* __restrict__ key_s, const u64* __restrict__ srcs, float4* s_buf,
+                                            uint32_t* s_red) {
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * B3F + tid;
     const bool live = i < P.n;
@@ -675,7 +678,7 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
         __syncthreads();     // the next plane reuses s_buf / s_red
     }
     if (!live) return;
-    float4 v = mv, p = pos_s[i];
+    float4 v = mv, p = pos_s[(uint32_t)srcs[i]];        // pos_s: the PREVIOUS state, source order (see k3_reorder)
     const float ax = A.px + A.vx * P.visc_coeff, ay = A.py + A.vy * P.visc_coeff, az = A.pz + A.vz * P.visc_coeff;
     v.x += __fdiv_rn(ax, mrho) * P.dt; v.y += __fdiv_rn(ay, mrho) * P.dt; v.z += __fdiv_rn(az, mrho) * P.dt;
     v.x += P.gx * P.dt; v.y += P.gy * P.dt; v.z += P.gz * P.dt;
@@ -699,24 +702,25 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
 template <int MODE> __global__ void k3_force(Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s,
                                              const float4* __restrict__ pred, const uint32_t* __restrict__ cs,
                                              float4* __restrict__ pos_out, float4* __restrict__ vel_out,
-                                             const u64m* __restrict__ masks, const uint32_t* __restrict__ key_s);
+                                             const u64m* __restrict__ masks, const uint32_t* __restrict__ key_s,
+                                             const u64* __restrict__ srcs);
 template <>
 __global__ __launch_bounds__(B3F) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES, FS3_FORCE_WAVES))) void k3_force<0>(
     Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
     const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks,
-    const uint32_t* __restrict__ key_s) {
+    const uint32_t* __restrict__ key_s, const u64* __restrict__ srcs) {
     __shared__ float4 s_buf[TILE3_LDS];           // the staged plane
     __shared__ uint32_t s_red[24];
-    force3_body<0>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, s_buf, s_red);
+    force3_body<0>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, srcs, s_buf, s_red);
 }
 template <>
 __global__ __launch_bounds__(B3F) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_WAVES_TOL, FS3_FORCE_WAVES_TOL))) void k3_force<2>(
     Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
     const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks,
-    const uint32_t* __restrict__ key_s) {
+    const uint32_t* __restrict__ key_s, const u64* __restrict__ srcs) {
     __shared__ float4 s_buf[TILE3_LDS];
     __shared__ uint32_t s_red[24];
-    force3_body<2>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, s_buf, s_red);
+    force3_body<2>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, srcs, s_buf, s_red);
 }
 
 __global__ __launch_bounds__(B3) void k3_export(uint32_t n, const float4* __restrict__ pos, const float4* __restrict__ pred,
@@ -885,8 +889,10 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     if (tol) hipLaunchKernelGGL(k3_density<2>, gridf, blockf, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
     else hipLaunchKernelGGL(k3_density<0>, gridf, blockf, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
     if (ev) H3(hipEventRecord(ev[4], st));
-    if (tol) hipLaunchKernelGGL(k3_force<2>, gridf, blockf, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm, s->key.p);
-    else hipLaunchKernelGGL(k3_force<0>, gridf, blockf, 0, st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos.p, s->vel.p, fm, s->key.p);
+    // positions ping-pong: read the previous state (s->pos, source order) through the pairs, write the new one into s->pos_s
+    if (tol) hipLaunchKernelGGL(k3_force<2>, gridf, blockf, 0, st, P, s->pos.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos_s.p, s->vel.p, fm, s->key.p, s->pairs.p);
+    else hipLaunchKernelGGL(k3_force<0>, gridf, blockf, 0, st, P, s->pos.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos_s.p, s->vel.p, fm, s->key.p, s->pairs.p);
+    { float4* t = s->pos.p; s->pos.p = s->pos_s.p; s->pos_s.p = t; }
     if (ev) { H3(hipEventRecord(ev[5], st)); s->pending += 1; }
     H3(s->sortp.step_enqueued(st));
     H3(hipGetLastError());
