@@ -260,3 +260,44 @@ def test_3d_mask_handoff_does_not_change_a_bit(fs, tmp_path):
         outs.append(np.load(out))
     assert np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8))
     assert np.array_equal(outs[0].view(np.uint8), outs[2].view(np.uint8))
+
+
+@pytest.mark.parametrize("seed,coincident", [(1, False), (2, True)])
+def test_oracle3d_equals_independent_python_restatement(fs, orc, seed, coincident):
+    """The 3D statement has no reference counterpart, so the C++ 3D oracle is cross-checked by a second restatement in
+    pure Python with np.float32 scalars (tests/pyref3d.py): 3 steps of ~90 jittered particles with velocities, optionally
+    with a coincident triple (PRNG direction, r = 0 viscosity), bit for bit on every field."""
+    import pyref3d
+    f = np.float32
+    side = 4 if coincident else 5
+    n = side ** 3
+    st = fs.Settings3(n, 0.1, 0.2, fs.Vec3(1.6, 1.2, 1.4))
+    tick = fs.TickSettings3(float(f(1) / f(120)), fs.Vec3(0.3, 9.81, -0.2), 1.0, 50.0, 0.0, 0.1, 25.0)
+    o = orc.OracleSim3D(st, (0.05, 0.1, -0.05))
+    rng = np.random.default_rng(seed)
+    p = o.particles()
+    p["position"] += rng.uniform(-0.04, 0.04, size=(n, 3)).astype(f)
+    if coincident:
+        p["position"][1:3] = p["position"][0]
+    p["predicted_position"] = p["position"]
+    p["velocity"] = rng.uniform(-2, 2, size=(n, 3)).astype(f)
+    if coincident:
+        p["velocity"][5] = (400.0, -450.0, 300.0)            # the 500 clamp and a wall bounce
+    o.set_particles(p)
+    parts = [dict(pos=tuple(f(x) for x in r["position"]), pred=tuple(f(x) for x in r["predicted_position"]),
+                  vel=tuple(f(x) for x in r["velocity"]), density=f(r["density"]), grid=int(r["grid"])) for r in p]
+    for s in range(3):
+        o.step(tick)
+        poly6, spiky, visc = o.constants()
+        u = dict(grid=o.grid_dims, h=f(st.smoothing_radius), dt=f(tick.delta), size=(f(st.size.x), f(st.size.y), f(st.size.z)),
+                 mass=f(tick.mass), k=f(tick.pressure_constant), rho0=f(tick.rest_density), damping=f(tick.damping_factor),
+                 visc_coeff=f(tick.viscosity_coefficient), gravity=(f(tick.gravity.x), f(tick.gravity.y), f(tick.gravity.z)),
+                 poly6=f(poly6), spiky=f(spiky), visc=f(visc), tick=s + 1)
+        pyref3d.step3(parts, u)
+        want = o.particles()
+        assert [q["grid"] for q in parts] == list(want["grid"]), f"step {s}: keys / order"
+        for name, key in (("position", "pos"), ("predicted_position", "pred"), ("velocity", "vel")):
+            got = np.array([q[key] for q in parts], dtype=f)
+            assert np.array_equal(got.view(np.uint32), want[name].view(np.uint32)), f"step {s}: {name}"
+        got = np.array([q["density"] for q in parts], dtype=f)
+        assert np.array_equal(got.view(np.uint32), want["density"].view(np.uint32)), f"step {s}: density"
