@@ -121,15 +121,27 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_lookback(uint32_t* __restri
     if (total_out && base < count && base + SCAN_ITEMS >= count) *total_out = run;   // the thread that owns item count - 1
 }
 
+// Four slots per thread, 256 apart: the three dependent loads of a slot (kt -> cs -> store address) of all four are in flight
+// together (the kernel is latency-bound at a slab rank's size).
+#define SC_ITEMS 4
 __global__ __launch_bounds__(CS_BLOCK) void k_cs_scatter(uint32_t n, uint32_t ncell, const u64* __restrict__ kt,
                                                          const uint32_t* __restrict__ cs, uint32_t* __restrict__ slot_src) {
-    const uint32_t i = blockIdx.x * CS_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const u64 e = kt[i];
-    const uint32_t kk = (uint32_t)(e >> 32);
-    if (kk == FS_DEAD_KEY) return;                                  // slab mode: an empty slot
-    const uint32_t k = kk < ncell ? kk : ncell - 1u;
-    slot_src[cs[k] + (uint32_t)e] = i;
+    const uint32_t i0 = blockIdx.x * (CS_BLOCK * SC_ITEMS) + threadIdx.x;
+    u64 e[SC_ITEMS];
+#pragma unroll
+    for (int it = 0; it < SC_ITEMS; ++it) {
+        const uint32_t i = i0 + (uint32_t)it * CS_BLOCK;
+        e[it] = i < n ? kt[i] : ((u64)FS_DEAD_KEY << 32);
+    }
+    uint32_t start[SC_ITEMS];
+#pragma unroll
+    for (int it = 0; it < SC_ITEMS; ++it) {
+        const uint32_t kk = (uint32_t)(e[it] >> 32);
+        start[it] = kk == FS_DEAD_KEY ? 0u : cs[kk < ncell ? kk : ncell - 1u];     // DEAD: slab mode, an empty slot
+    }
+#pragma unroll
+    for (int it = 0; it < SC_ITEMS; ++it)
+        if ((uint32_t)(e[it] >> 32) != FS_DEAD_KEY) slot_src[start[it] + (uint32_t)e[it]] = i0 + (uint32_t)it * CS_BLOCK;
 }
 
 // Fused rank fix-up + reorder pass (k_reorder<false> / k_slab_reorder<false> of round 2).  SLAB: `n` = slot capacity,
@@ -210,7 +222,7 @@ void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, ui
     const CsLayout L = cs_layout(scratch, cap, ncell_alloc);
     const uint32_t count = ncell + 1u, tiles = (count + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_scan_lookback, dim3(tiles), dim3(SCAN_BLOCK), 0, st, L.hist, count, cs, L.state, L.ticket, epoch, n_live_out);
-    hipLaunchKernelGGL(k_cs_scatter, dim3((cap + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, cap, ncell, L.kt, cs, L.slot_src);
+    hipLaunchKernelGGL(k_cs_scatter, dim3((cap + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), dim3(CS_BLOCK), 0, st, cap, ncell, L.kt, cs, L.slot_src);
 }
 void launch_counting_reorder_slab(hipStream_t st, const StepParams& P, uint32_t cap, uint32_t ncell_alloc, uint32_t* scratch, u64* pairs,
                                   const uint32_t* cs, const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s,
@@ -229,7 +241,7 @@ void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos
     hipLaunchKernelGGL(k_cs_hist, grid, block, 0, st, P, pos, vel, L.kt, L.hist, gap_counter, safe);
     hipLaunchKernelGGL(k_scan_lookback, dim3((count + SCAN_TILE - 1) / SCAN_TILE), dim3(SCAN_BLOCK), 0, st, L.hist, count, cs, L.state, L.ticket,
                        epoch, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_cs_scatter, grid, block, 0, st, n, ncell, L.kt, cs, L.slot_src);
+    hipLaunchKernelGGL(k_cs_scatter, dim3((n + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), block, 0, st, n, ncell, L.kt, cs, L.slot_src);
 }
 void launch_counting_reorder(hipStream_t st, const StepParams& P, uint32_t* scratch, u64* pairs, const uint32_t* cs,
                              const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s,
