@@ -464,44 +464,65 @@ __device__ __forceinline__ void force_sweep_chunks(const StepParams& P, const Ro
         const uint32_t hi = r == 0 ? hi0 : r == 1 ? hi1 : hi2;
         const uint32_t b0 = r == 0 ? b00 : r == 1 ? b01 : b02;
         const uint32_t len = hi - lo;
+        // Round 3: FS_CHUNK_BATCH chunks of 32 candidates are scanned before the walk starts, and their masks are walked as
+        // ONE shift register (cur <- n1 <- n2 <- n3; the chunks of a batch are consecutive in the row, so a refill only
+        // advances the two bases by 32 candidates).  With one chunk per walk a lane waited for the wave's slowest lane after
+        // every ~11 hits (lane utilisation 0.66 in the dense regime, profiles/r03_counters_2d_dense.md); over 128
+        // candidates the hit counts of the lanes differ relatively less.
+#ifndef FS_CHUNK_BATCH
+#define FS_CHUNK_BATCH 4
+#endif
 #pragma unroll 1
-        for (uint32_t c0 = 0; __any(c0 < len); c0 += 32u) {              // c0 is wave-uniform
-            const uint32_t clen = c0 < len ? (len - c0 < 32u ? len - c0 : 32u) : 0u;
-            const uint32_t g = clen ? lo + c0 : 0u;                      // global index of the chunk's first candidate
-            // byte offset of the chunk's first candidate: into the LDS tile, or (32-bit, n <= 2^28) into pred
-            const uint32_t boff = (STAGED ? (clen ? (uint32_t)r * NBF_ROW + (g - b0) : 0u) : g) << 3;
+        for (uint32_t c0 = 0; __any(c0 < len); c0 += 32u * FS_CHUNK_BATCH) {   // c0 is wave-uniform
+            uint32_t mq[FS_CHUNK_BATCH];
+            const uint32_t g0 = c0 < len ? lo + c0 : 0u;                  // global index of the batch's first candidate
+            // byte offset of the batch's first candidate: into the LDS tile, or (32-bit, n <= 2^28) into pred
+            const uint32_t boff0 = (STAGED ? (c0 < len ? (uint32_t)r * NBF_ROW + (g0 - b0) : 0u) : g0) << 3;
             const char* src = STAGED ? reinterpret_cast<const char*>(s_flat) : reinterpret_cast<const char*>(pred);
-#define FS_CAND(k) (*reinterpret_cast<const float2*>(src + (boff + ((k) << 3))))
-            uint32_t mask = 0, t = 0;
-            for (; __any(t < clen); t += 4u) {
-                const float2 q0 = FS_CAND(t), q1 = FS_CAND(t + 1u), q2 = FS_CAND(t + 2u), q3 = FS_CAND(t + 3u);
-                const float2 qq[4] = {q0, q1, q2, q3};
+#define FS_CAND(off, k) (*reinterpret_cast<const float2*>(src + ((off) + ((k) << 3))))
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float ox = qq[u].x - me.x, oyv = qq[u].y - me.y;
-                    shift_in_not_greater(mask, ox * ox + oyv * oyv, lim);
+            for (int q = 0; q < FS_CHUNK_BATCH; ++q) {
+                const uint32_t cq = c0 + 32u * (uint32_t)q;
+                const uint32_t clen = cq < len ? (len - cq < 32u ? len - cq : 32u) : 0u;
+                const uint32_t boff = clen ? boff0 + 256u * (uint32_t)q : 0u;
+                uint32_t mask = 0, t = 0;
+                for (; __any(t < clen); t += 4u) {
+                    const float2 q0 = FS_CAND(boff, t), q1 = FS_CAND(boff, t + 1u), q2 = FS_CAND(boff, t + 2u), q3 = FS_CAND(boff, t + 3u);
+                    const float2 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float ox = qq[u].x - me.x, oyv = qq[u].y - me.y;
+                        shift_in_not_greater(mask, ox * ox + oyv * oyv, lim);
+                    }
                 }
+                mask = t ? mask << (32u - t) : 0u;
+                mask &= clen ? 0xFFFFFFFFu << (32u - clen) : 0u;
+                const uint32_t g = g0 + 32u * (uint32_t)q;
+                if (r == 1 && clen && ii - g < clen) mask &= ~(0x80000000u >> (ii - g));   // k != i
+                mq[q] = mask;
             }
-            mask = t ? mask << (32u - t) : 0u;
-            mask &= clen ? 0xFFFFFFFFu << (32u - clen) : 0u;
-            if (r == 1 && ii - g < clen) mask &= ~(0x80000000u >> (ii - g));   // k != i
-            // walk, software-pipelined by one neighbour
+            // walk, software-pipelined by one neighbour; (boff, goff) are the bases of the chunk `cur` belongs to
+            uint32_t cur = mq[0], n1 = FS_CHUNK_BATCH > 1 ? mq[1 % FS_CHUNK_BATCH] : 0u, n2 = FS_CHUNK_BATCH > 2 ? mq[2 % FS_CHUNK_BATCH] : 0u,
+                     n3 = FS_CHUNK_BATCH > 3 ? mq[3 % FS_CHUNK_BATCH] : 0u;
+            uint32_t boff = boff0, goff = g0 << 3;
             float2 qn = make_float2(0.0f, 0.0f), vn = qn, dn = qn;
-            bool have = false;
+            bool have = false, pending = false;
 #define FS_FETCH_NEXT1()                                                                                             \
     do {                                                                                                             \
-        have = mask != 0u;                                                                                           \
+        if (cur == 0u) { cur = n1; n1 = n2; n2 = n3; n3 = 0u; boff += 256u; goff += 256u; }   /* next chunk of the batch */ \
+        have = cur != 0u;                                                                                            \
+        pending = (cur | n1 | n2 | n3) != 0u;            /* an empty chunk in the middle costs this lane one idle trip */ \
         if (have) {                                                                                                  \
-            const uint32_t tt = (uint32_t)__builtin_clz(mask);                                                       \
-            mask ^= 0x80000000u >> tt;                                                                               \
-            qn = FS_CAND(tt);                                                                                        \
-            const uint32_t off = (g + tt) << 3;                                                                      \
+            const uint32_t t8 = (uint32_t)__builtin_clz(cur) << 3;                                                   \
+            cur ^= 0x80000000u >> (t8 >> 3);                                                                         \
+            qn = FS_CAND(boff, t8 >> 3);                                                                             \
+            const uint32_t off = goff + t8;                                                                          \
             vn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vel_s) + off);                       \
             dn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rho2) + off);                        \
         }                                                                                                            \
     } while (0)
             FS_FETCH_NEXT1();
-            while (__any(have)) {
+            while (__any(pending)) {
                 const bool cur_valid = have;
                 const float2 q0 = qn, v0 = vn, d0 = dn;
                 FS_FETCH_NEXT1();
