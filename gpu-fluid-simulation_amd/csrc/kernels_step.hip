@@ -824,10 +824,16 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
         const float s2 = __builtin_fmaf(v.x, v.x, v.y * v.y);
         if (s2 > 250000.0f) { const float k = 500.0f * __builtin_amdgcn_rsqf(s2); v.x *= k; v.y *= k; }
     } else {
-        const float speed = sqrt_rn(v.x * v.x + v.y * v.y);
-        if (speed > 500.0f) {
-            v.x = __fdiv_rn(v.x, speed) * 500.0f;
-            v.y = __fdiv_rn(v.y, speed) * 500.0f;
+        // compute.wgsl:118-122.  The square root (an IEEE sequence of ~15 instructions) is only needed near the clamp:
+        // for s2 <= 249 000 it is at most 498.999 < 500 whatever the rounding, so nothing can change; NaN was reset
+        // above and an infinite s2 takes the branch.
+        const float s2 = v.x * v.x + v.y * v.y;
+        if (s2 > 249000.0f) {
+            const float speed = sqrt_rn(s2);
+            if (speed > 500.0f) {
+                v.x = __fdiv_rn(v.x, speed) * 500.0f;
+                v.y = __fdiv_rn(v.y, speed) * 500.0f;
+            }
         }
     }
     p.x += v.x * P.dt;

@@ -683,9 +683,12 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
     v.x += __fdiv_rn(ax, mrho) * P.dt; v.y += __fdiv_rn(ay, mrho) * P.dt; v.z += __fdiv_rn(az, mrho) * P.dt;
     v.x += P.gx * P.dt; v.y += P.gy * P.dt; v.z += P.gz * P.dt;
     if (!(v.x == v.x && v.y == v.y && v.z == v.z)) { v.x = 0.0f; v.y = 0.0f; v.z = 0.0f; }
-    const float speed = sqrt_rn(v.x * v.x + v.y * v.y + v.z * v.z);
-    if (speed > 500.0f) {
-        v.x = __fdiv_rn(v.x, speed) * 500.0f; v.y = __fdiv_rn(v.y, speed) * 500.0f; v.z = __fdiv_rn(v.z, speed) * 500.0f;
+    const float s2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (s2 > 249000.0f) {                           // below that the root is < 500 whatever the rounding: no clamp (kernels_step.hip)
+        const float speed = sqrt_rn(s2);
+        if (speed > 500.0f) {
+            v.x = __fdiv_rn(v.x, speed) * 500.0f; v.y = __fdiv_rn(v.y, speed) * 500.0f; v.z = __fdiv_rn(v.z, speed) * 500.0f;
+        }
     }
     p.x += v.x * P.dt; p.y += v.y * P.dt; p.z += v.z * P.dt;
     if (fabsf(p.x) > P.bx) { p.x = P.bx * sign_f32(p.x); v.x *= -1.0f * P.damping; }
