@@ -90,6 +90,7 @@ struct SortPlan {
                                    // once when not needed, ~5 us apiece), 1 one persistent launch (slow when it has work)
     uint32_t* feedback = nullptr;  // host-visible words the certificate reports to (stage, verdict, fit class, seq), or none
     uint32_t seq = 0;
+    int inject_timeout = 0;        // tests (FS_SORT_INJECT_TIMEOUT=1): the stand-by kernel reports a barrier time-out it did not have
 };
 // keygen3d != nullptr (3D engine): the same fusion with float4 pos / vel and the 3D cell key.
 struct KeyGen3 { float dt, h, bx, by, bz; uint32_t gw, gh; };

@@ -739,9 +739,14 @@ __device__ __forceinline__ void fallback_pass(bool flip, u64* pairs, uint32_t n,
 // sort_policy.h), correct for any input, several times slower than the per-stage launches when it has real work
 // (16M: ~3.5 ms against 0.25 ms of per-stage launches: every barrier is an L2 write-back and invalidate).
 __global__ __launch_bounds__(256) void k_late_fallback(u64* pairs, uint32_t n, uint32_t p2, uint32_t S, uint32_t s0,
-                                                       uint32_t* dirty, uint32_t* plan) {
+                                                       uint32_t* dirty, uint32_t* plan, uint32_t inject_timeout) {
     if (plan[0] != SORT_NO_PLAN) return;               // uniform over the grid: the shifted merge did the work
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&plan[6], 1u);   // diagnostics: calls this kernel had to work in
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&plan[6], 1u);                       // diagnostics: calls this kernel had to work in
+        // tests only: report a time-out that did not happen (the barriers still hold, the sort stays correct), so that
+        // the host's reaction — fs_step fails with FS_ERR_DEVICE from then on — has a test (tests/test_sort_gpu.py)
+        if (inject_timeout) atomicAdd(&plan[4], 1u);
+    }
     __shared__ u64 s[LT<4>::LDS];                       // 256 threads: the 16-element form of the tile code
     __shared__ uint32_t s_first[256], s_last[256];
     __shared__ uint32_t s_active;
@@ -904,7 +909,8 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
                     int v = e ? atoi(e) : (cus > 128 ? 128 : cus);   // 16M, 16 working calls in 110: 64: sort 1.08 ms avg, 128: 1.01, 256: 1.12
                     return v < 1 ? 1 : (v > 256 ? 256 : v);
                 }();
-                hipLaunchKernelGGL(k_late_fallback, dim3(fb_grid), dim3(256), 0, st, pairs, n, p2, S, s0, dirty, gate);
+                hipLaunchKernelGGL(k_late_fallback, dim3(fb_grid), dim3(256), 0, st, pairs, n, p2, S, s0, dirty, gate,
+                                   plan && plan->inject_timeout ? 1u : 0u);
                 return launches + 1;
             }
         }

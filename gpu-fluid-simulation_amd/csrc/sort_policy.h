@@ -31,6 +31,7 @@ struct SortPolicy {
     int trusted = 0;                // consecutive passing reports
     bool enabled = false;
     bool force_single = false;      // FS_SORT_TRUST=1 (tests): the single stand-by launch from the first step on
+    bool inject_timeout = false;    // FS_SORT_INJECT_TIMEOUT=1 (tests): drives the host's handling of a barrier time-out
     int fixed_stage = -1;           // FS_SORT_FUSE_STAGE at create: a fixed stage (0: per-stage launches only), no policy
     int start_back = 8;             // first guess: S - start_back
     hipEvent_t flight[FLIGHT] = {};
@@ -43,6 +44,7 @@ struct SortPolicy {
         const char* tr = getenv("FS_SORT_TRUST");
         if (fx) fixed_stage = atoi(fx);
         force_single = tr && atoi(tr) != 0;
+        { const char* inj = getenv("FS_SORT_INJECT_TIMEOUT"); inject_timeout = inj && atoi(inj) != 0; }
         enabled = !(e && atoi(e) == 0) && !fx;
         // the words are allocated even when the plan policy is off: fb[6] is the force pass's work report (general_grid())
         hipError_t r = hipHostMalloc((void**)&fb, 8 * sizeof(uint32_t), hipHostMallocMapped);
@@ -119,6 +121,7 @@ struct SortPolicy {
         out->fallback = single_standby() ? 1 : 0;
         out->feedback = fb;
         out->seq = ++seq;
+        out->inject_timeout = inject_timeout ? 1 : 0;
         return true;
     }
 };

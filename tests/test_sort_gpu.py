@@ -167,3 +167,40 @@ def test_upload_of_a_shuffled_state_mid_run(fs, monkeypatch):
     assert got.tobytes() == base.tobytes() and info["timeouts"] == 0
     forced, info = _run(fs, n, 40, {"FS_SORT_TRUST": "1"}, monkeypatch, disturb)
     assert forced.tobytes() == base.tobytes() and info["standby_runs"] >= 1 and info["timeouts"] == 0
+
+
+def test_a_barrier_time_out_report_kills_the_handle(fs, monkeypatch):
+    """include/fluidsim.h: after the stand-by kernel reports a grid-barrier time-out, fs_step fails with FS_ERR_DEVICE and
+    keeps failing (the handle is dead; destroy it).  The report is injected (FS_SORT_INJECT_TIMEOUT: the barriers
+    themselves hold), what is under test is the host's reaction; other handles of the process are not affected."""
+    n = 1 << 18
+    monkeypatch.setenv("FS_SORT_TRUST", "1")              # the single stand-by launch from the first step on
+    monkeypatch.setenv("FS_SORT_INJECT_TIMEOUT", "1")
+    st, off, tick = fs.dam_break_2d(n)
+    sim = fs.FluidSimulation(st, device=0, initial_offset=off)
+    monkeypatch.delenv("FS_SORT_TRUST")
+    monkeypatch.delenv("FS_SORT_INJECT_TIMEOUT")
+    rng = np.random.default_rng(11)
+    p = sim.download_particles()
+    sim.upload_particles(p[rng.permutation(n)])           # an arbitrary order: the certificate fails, the stand-by kernel works
+    failed_at = None
+    for i in range(30):
+        try:
+            sim.tick(tick)
+        except fs.FluidSimError as e:
+            assert e.status == fs._abi.FS_ERR_DEVICE and "timed out" in str(e)
+            failed_at = i
+            break
+    assert failed_at is not None and failed_at >= 1       # reported by the certificate of a LATER step
+    info = sim.sort_plan()
+    assert info["timeouts"] >= 1 and info["standby_runs"] >= 1
+    for _ in range(3):                                    # terminal: every later step fails the same way
+        with pytest.raises(fs.FluidSimError) as ei:
+            sim.tick(tick)
+        assert ei.value.status == fs._abi.FS_ERR_DEVICE
+    sim.download_particles()                              # reading the state back still works (diagnosis)
+    del sim
+    other = fs.FluidSimulation(st, device=0, initial_offset=off)       # a fresh handle is healthy
+    for _ in range(5):
+        other.tick(tick)
+    assert other.sort_plan()["timeouts"] == 0
