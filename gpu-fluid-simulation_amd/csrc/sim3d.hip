@@ -34,7 +34,25 @@ struct Params3 {
     ConstDiv div_2h3, div_h2;    // exact constant divisions, proven at create (fs_device.h div_const)
     int32_t share_div;           // one reciprocal per denominator + div_by_rcp in the force pass (fs_device.h)
     int32_t handoff;             // k3_density stores its nine 64-bit pass masks per particle, k3_force walks them (no second scan)
+    uint32_t xcd_chunk_log2;     // xcd_block3(): blocks per chunk dealt to one XCD
 };
+
+// Workgroup -> block of particles for the density / force kernels, XCD-aware as in 2D (fs_device.h xcd_block): the
+// hardware deals consecutive workgroup ids round-robin to the 8 XCDs, and a block's nine sweep rows are the rows of the
+// blocks 3 (next cell row) and ~310 (next z-plane) away — dealt block by block, EVERY XCD's L2 fetches every row.  Chunks
+// of 2^c consecutive blocks per XCD keep the y-neighbour rows in one L2.  Grid: xcd_grid3() blocks.
+__device__ __forceinline__ bool xcd_block3(const Params3& P, uint32_t nblocks, uint32_t* logical) {
+    const uint32_t c = P.xcd_chunk_log2;
+    const uint32_t slot = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const uint32_t chunk = ((slot >> c) << 3) | xcd;
+    const uint32_t lb = (chunk << c) | (slot & ((1u << c) - 1u));
+    *logical = lb;
+    return lb < nblocks;
+}
+static inline uint32_t xcd_grid3(uint32_t nb, uint32_t c) {
+    const uint32_t chunks = (nb + (1u << c) - 1u) >> c;
+    return (((chunks + 7u) >> 3) << 3) << c;
+}
 
 #define B3 256
 
@@ -141,14 +159,29 @@ __device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
 #endif
 #define W3F (B3F / 64)
 #if B3F == 256
+#ifndef TILE3
 #define TILE3 384            // staged candidates per sweep row; one z-plane (3 rows) is staged at a time
+#endif
+#ifdef FS3_ROW_PAD           // round-2 layout (A/B): every row with its own 64 entries of scan slack
 #define TILE3_ROW (TILE3 + 64)
+#else
+#define TILE3_ROW TILE3      // rows 0 and 1 over-read into the next row's stage (masked off), only the last row needs the slack
+#endif
 #else
 #define TILE3 96             // a wave's row at rest: 10 cells x 8 particles; longer rows take the unstaged chunked sweep
 #define TILE3_ROW TILE3      // rows 0 and 1 over-read into the next row's stage, only the last row needs the slack below
 #endif
 #define TILE3_PAD 72u        // the wave-uniform scan reads up to the wave's longest row (<= 64) + 3 past a lane's own range
 #define TILE3_LDS (3 * TILE3_ROW + TILE3_PAD)
+// k3_force stages the neighbours' VELOCITY records {vx, vy, vz, +-1/rho} behind the positions, same row pitch: the walk's
+// second fetch is then an LDS read at a constant offset from the first instead of a 16-byte gather per neighbour (with the
+// masks handed over the kernel was bound by exactly those gathers: waves parked 65 - 79 %, profiles/r03_counters_3d*.md).
+// 19.6 + 18.4 KB per workgroup: four workgroups (16 waves) per CU.
+#ifndef FS3_STAGE_VEL
+#define FS3_STAGE_VEL 1
+#endif
+#define TILE3_VEL_OFF (TILE3_LDS * 16u)          // bytes from a staged position to the same candidate's velocity
+#define TILE3_FORCE_LDS (TILE3_LDS + (FS3_STAGE_VEL ? 3 * TILE3_ROW : 0))
 typedef unsigned long long u64m;
 
 // ---- pass masks of one staged z-plane -----------------------------------------------------------------------
@@ -159,6 +192,9 @@ typedef unsigned long long u64m;
 // (TILE3_ROW entries per row).  Both the density and the force pass need exactly these masks: k3_density computes
 // them, walks them for its own sum and (Params3::handoff) stores them — 72 B per particle — so that k3_force does not
 // scan the 216 candidates a second time (~2 600 of its ~9 900 VALU instructions per wave).
+__device__ __forceinline__ void shift_in_not_greater32(uint32_t& mask, float r2, float lim) {
+    asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
+}
 __device__ __forceinline__ void shift_in_not_greater64(uint32_t& lo, uint32_t& hi, float r2, float lim) {
     asm("v_cmp_nlt_f32 vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
         : "+v"(lo), "+v"(hi) : "v"(r2), "s"(lim) : "vcc");
@@ -176,6 +212,37 @@ __device__ __forceinline__ void scan3_plane(const Params3& P, const RowRanges& R
         la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
         const float4* base = s_flat + la[r];
         uint32_t mlo = 0, mhi = 0, t = 0;
+#ifndef FS3_SCAN64
+        // Two 32-bit shift registers, one v_addc_co per candidate (the 64-bit form needs two): candidates 0 .. 31 go
+        // through `mhi`, the rest through `mlo`; t is wave-uniform, so the switch is a scalar branch.
+        for (; t < 32u && __any(t < len); t += 4u) {
+            const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
+            const float4 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
+                shift_in_not_greater32(mhi, ox * ox + oy * oy + oz * oz, lim);
+            }
+        }
+        const uint32_t ta = t;                                            // <= 32: candidates that went through mhi
+        for (; __any(t < len); t += 4u) {
+            const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
+            const float4 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
+                shift_in_not_greater32(mlo, ox * ox + oy * oy + oz * oz, lim);
+            }
+        }
+        {   // candidate k sits at bit 63 - k: left-align each half, keep the lane's own len candidates
+            const uint32_t hi32 = ta ? mhi << (32u - ta) : 0u;
+            const uint32_t lo32 = t > ta ? mlo << (32u - (t - ta)) : 0u;
+            u64m mask = ((u64m)hi32 << 32) | lo32;
+            mask &= len ? ~0ull << (64u - len) : 0ull;
+            m[r] = mask;
+        }
+        continue;
+#endif
         for (; __any(t < len); t += 4u) {                                 // t is wave-uniform
 #ifdef FS3_B96
             if (XYZ_ONLY) {
@@ -238,7 +305,9 @@ __global__ __launch_bounds__(B3F) FS3_DENSITY_ATTR void k3_density(Params3 P, fl
                                                  const uint32_t* __restrict__ key_s) {
     __shared__ float4 s_pred[TILE3_LDS];
     __shared__ uint32_t s_red[24];
-    const uint32_t i = blockIdx.x * B3F + threadIdx.x;
+    uint32_t blk;
+    if (!xcd_block3(P, (P.n + B3F - 1) / B3F, &blk)) return;       // uniform
+    const uint32_t i = blk * B3F + threadIdx.x;
     const bool live = i < P.n;
     const float4 me = pred[live ? i : P.n - 1];
     const uint32_t key = key_s[live ? i : P.n - 1];
@@ -423,7 +492,7 @@ __device__ __forceinline__ Terms3 pair3(const Params3& P, float4 me, float4 mv, 
 // (the general sweep, sweep3_chunks, follows the mask sweep below: it shares its helpers)
 
 #ifndef FS3_FORCE_WAVES
-#define FS3_FORCE_WAVES 7   // round 2 (own scan): 4: 2.265, 5: 2.232, 6: 2.215 ms.  Round 3 (masks handed over by k3_density), steps 10-50 / 50-110: 5: 1.42 / 2.48, 6: 1.45 / 2.45, 7: 1.38 / 2.38 ms
+#define FS3_FORCE_WAVES (FS3_STAGE_VEL ? 4 : 7)   // with the velocity stage the LDS allows 4 waves per SIMD: take their registers.  Without it: round 2 (own scan): 4: 2.265, 5: 2.232, 6: 2.215 ms.  Round 3 (masks handed over by k3_density), steps 10-50 / 50-110: 5: 1.42 / 2.48, 6: 1.45 / 2.45, 7: 1.38 / 2.38 ms
 #endif
 
 // ---- tolerance mode (fs3_create_ex math_mode = FS_MATH_TOLERANCE): the pressure and viscosity terms of one in-radius
@@ -511,7 +580,7 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, co
     // tolerance mode) — but the second neighbour in flight costs 16 more registers, and with 72 - 80 already in use
     // (and 180 - 200 bytes of scratch in the chunked paths) that loses more than it covers.
 #ifndef FS3_PIPE_DEPTH
-#define FS3_PIPE_DEPTH 1      // depth 2 measured slower at every register budget (profiles/r03_rejected.md): 8 M, strict 1.95 -> 2.05 .. 2.37 ms
+#define FS3_PIPE_DEPTH (FS3_STAGE_VEL ? 2 : 1)      // without the velocity stage (7 waves, 72 registers) depth 2 measured slower at every register budget (profiles/r03_rejected.md): 8 M, strict 1.95 -> 2.05 .. 2.37 ms
 #endif
 #define FS3_FETCH(have, qn, vn)                                                                                      \
     do {                                                                                                             \
@@ -521,7 +590,8 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, co
             cur ^= 0x8000000000000000ull >> t;                                                                       \
             qn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_flat) + (lac + (t << 4)));         \
             /* 32-bit byte offset from the SGPR base (n <= 2^28) instead of 64-bit address arithmetic */             \
-            vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + ((loc + t) << 4));          \
+            if (FS3_STAGE_VEL) vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_flat) + (lac + (t << 4)) + TILE3_VEL_OFF); \
+            else vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + ((loc + t) << 4));     \
             if (cur == 0ull) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }     \
         }                                                                                                            \
     } while (0)
@@ -561,9 +631,6 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, co
 // kernels_step.hip force_sweep_chunks) — wave-uniform scan into a 32-bit mask, pipelined walk.  Rows and
 // chunks in order = the oracle's visiting order.  STAGED: candidates from the LDS tile, else from global
 // memory (pred is allocated with FS_PRED_SLACK elements of slack for the read-ahead).
-__device__ __forceinline__ void shift_in_not_greater32(uint32_t& mask, float r2, float lim) {
-    asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
-}
 template <bool STAGED, int MODE>
 __device__ __forceinline__ void sweep3_chunks(const Params3& P, const Tol3& C, const RowRanges& R, const uint32_t* blo, bool self_plane,
                                               uint32_t ii, float4 me, float4 mv, float pressure,
@@ -608,7 +675,8 @@ __device__ __forceinline__ void sweep3_chunks(const Params3& P, const Tol3& C, c
             const uint32_t tt = (uint32_t)__builtin_clz(mask);                                                       \
             mask ^= 0x80000000u >> tt;                                                                               \
             qn = FS3_CAND(tt);                                                                                       \
-            vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + ((g + tt) << 4));           \
+            if (STAGED && FS3_STAGE_VEL) vn = *reinterpret_cast<const float4*>(src + (boff + (tt << 4)) + TILE3_VEL_OFF);  \
+            else vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + ((g + tt) << 4));      \
         }                                                                                                            \
     } while (0)
             FS3_FETCH_NEXT1();
@@ -635,7 +703,9 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
                                             const uint32_t* __restrict__ key_s, const u64* __restrict__ srcs, float4* s_buf,
                                             uint32_t* s_red) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t i = blockIdx.x * B3F + tid;
+    uint32_t blk;
+    if (!xcd_block3(P, (P.n + B3F - 1) / B3F, &blk)) return;       // uniform
+    const uint32_t i = blk * B3F + tid;
     const bool live = i < P.n;
     const uint32_t ii = live ? i : P.n - 1;
     const float4 me = pred[ii];
@@ -666,7 +736,10 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
         if (fit) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
-                for (uint32_t j = tid; j < bhi[r] - blo[r]; j += B3F) s_buf[r * TILE3_ROW + j] = pred[blo[r] + j];
+                for (uint32_t j = tid; j < bhi[r] - blo[r]; j += B3F) {
+                    s_buf[r * TILE3_ROW + j] = pred[blo[r] + j];
+                    if (FS3_STAGE_VEL) s_buf[TILE3_LDS + r * TILE3_ROW + j] = vel_s[blo[r] + j];
+                }
             __syncthreads();
             if (plane_masked(R, fit))     // the same predicate as k3_density: its masks exist exactly for these planes
                 sweep3_masks<MODE>(P, C, R, blo, plane == 1, ii, me, mv, pressure, vel_s, s_buf,
@@ -700,7 +773,7 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
 }
 // One kernel per math mode: the register budget that measured best differs (strict: 7 waves per SIMD, tolerance: 6).
 #ifndef FS3_FORCE_WAVES_TOL
-#define FS3_FORCE_WAVES_TOL 6
+#define FS3_FORCE_WAVES_TOL (FS3_STAGE_VEL ? 4 : 6)
 #endif
 template <int MODE> __global__ void k3_force(Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s,
                                              const float4* __restrict__ pred, const uint32_t* __restrict__ cs,
@@ -712,7 +785,7 @@ __global__ __launch_bounds__(B3F) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_W
     Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
     const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks,
     const uint32_t* __restrict__ key_s, const u64* __restrict__ srcs) {
-    __shared__ float4 s_buf[TILE3_LDS];           // the staged plane
+    __shared__ float4 s_buf[TILE3_FORCE_LDS];     // the staged plane: positions, then velocities
     __shared__ uint32_t s_red[24];
     force3_body<0>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, srcs, s_buf, s_red);
 }
@@ -721,7 +794,7 @@ __global__ __launch_bounds__(B3F) __attribute__((amdgpu_waves_per_eu(FS3_FORCE_W
     Params3 P, const float4* __restrict__ pos_s, const float4* __restrict__ vel_s, const float4* __restrict__ pred,
     const uint32_t* __restrict__ cs, float4* __restrict__ pos_out, float4* __restrict__ vel_out, const u64m* __restrict__ masks,
     const uint32_t* __restrict__ key_s, const u64* __restrict__ srcs) {
-    __shared__ float4 s_buf[TILE3_LDS];
+    __shared__ float4 s_buf[TILE3_FORCE_LDS];
     __shared__ uint32_t s_red[24];
     force3_body<2>(P, pos_s, vel_s, pred, cs, pos_out, vel_out, masks, key_s, srcs, s_buf, s_red);
 }
@@ -858,6 +931,15 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     // the classification bounds the pressure numerators by (1 + 2^-22) h spiky 2^39 <= 2^60 (fs_device.h)
     P.share_div = (s->share_div && h * P.spiky <= FS_HSPIKY_HI) ? 1 : 0;
     P.handoff = s->handoff ? 1 : 0;
+    {   // chunks of ~1/128 of the blocks, at most 2^7 (8 M: 31 250 blocks, a z-plane of the cube is ~310): FS3_XCD_CHUNK_LOG2 overrides
+        static const int forced = getenv("FS3_XCD_CHUNK_LOG2") ? atoi(getenv("FS3_XCD_CHUNK_LOG2")) : -1;
+        const uint32_t nb = (s->n + B3F - 1) / B3F;
+        uint32_t c = 0;
+        while (c < 7u && (128u << (c + 1u)) <= nb) ++c;
+        // 8 M, steps 10-110, strict / tolerance step (ms): c = 0: 3.329 / 2.732, 3: 3.277 / 2.675, 5: 3.260 / 2.645,
+        // 7: 3.255 / 2.636, 8: 3.281 / 2.650, 10: 3.403 / 2.738, 12: 3.425 / 2.761 (large chunks bind an XCD to one depth)
+        P.xcd_chunk_log2 = forced >= 0 ? (uint32_t)(forced > 16 ? 16 : forced) : c;
+    }
     const bool tol = s->math_mode == FS_MATH_TOLERANCE;
     hipStream_t st = s->stream;
     hipEvent_t* ev = nullptr;
@@ -888,7 +970,7 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     launch_fill_gaps(st, s->cs.p, s->work.p, s->counter.p, s->work_cap);
     if (ev) H3(hipEventRecord(ev[3], st));
     const fsd::u64* fm = s->handoff ? s->masks.p : nullptr;
-    const dim3 gridf((s->n + B3F - 1) / B3F), blockf(B3F);        // density / force: one-wave workgroups
+    const dim3 gridf(xcd_grid3((s->n + B3F - 1) / B3F, P.xcd_chunk_log2)), blockf(B3F);
     if (tol) hipLaunchKernelGGL(k3_density<2>, gridf, blockf, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
     else hipLaunchKernelGGL(k3_density<0>, gridf, blockf, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
     if (ev) H3(hipEventRecord(ev[4], st));

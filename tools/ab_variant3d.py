@@ -1,14 +1,20 @@
+"""A/B of a variant library on the 8 M 3D cube: python tools/ab_variant3d.py <default|v_x.so> [warm] [steps] [strict|tol]
+(variants: gpu-fluid-simulation_amd/build.py build(out=..., extra_flags=[...]))."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import gpu_fluid_simulation_amd as g
 from gpu_fluid_simulation_amd import _abi
 variant = sys.argv[1]
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+mode = sys.argv[4] if len(sys.argv) > 4 else "strict"
 if variant != "default":
     _abi._lib = _abi.load_library(os.path.join("gpu-fluid-simulation_amd", variant))
 st, off, tick = g.dam_break_3d(200 ** 3)
-sim = g.FluidSimulation3D(st, device=0, initial_offset=off)
-for _ in range(10): sim.tick(tick)
+sim = g.FluidSimulation3D(st, device=0, initial_offset=off,
+                          math_mode=_abi.FS_MATH_TOLERANCE if mode == "tol" else _abi.FS_MATH_IEEE)
+for _ in range(warm): sim.tick(tick)
 sim.sync(); sim.profile(True); sim.profile_read(True)
-ms = sim.timed_steps(tick, 40)
+ms = sim.timed_steps(tick, steps)
 p, k = sim.profile_read(True)
-print(variant, round(ms/40, 4), {a: round(b/40, 4) for a, b in p.items()})
+print(variant, mode, warm, steps, round(ms/steps, 4), {a: round(b/steps, 4) for a, b in p.items()})
