@@ -160,7 +160,7 @@ __device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
 #define W3F (B3F / 64)
 #if B3F == 256
 #ifndef TILE3
-#define TILE3 384            // staged candidates per sweep row; one z-plane (3 rows) is staged at a time
+#define TILE3 400            // staged candidates per sweep row; one z-plane (3 rows) is staged at a time.  8 M, steps 10-110, strict / tolerance step: 352: 3.30 / 2.70, 384: 3.21 / 2.60, 400: 3.18 / 2.56, 408: 3.18 / 2.56 ms (408 is the most four workgroups per CU have room for)
 #endif
 #ifdef FS3_ROW_PAD           // round-2 layout (A/B): every row with its own 64 entries of scan slack
 #define TILE3_ROW (TILE3 + 64)
