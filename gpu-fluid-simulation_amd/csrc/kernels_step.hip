@@ -127,7 +127,10 @@ __device__ __forceinline__ bool row_range(const StepParams& P, const uint32_t* _
 // straddle a grid-row end (or very sparse ones) exceed the tile and take the global path.
 #define NB_TILE 640          // staged candidates per sweep row
 #ifndef NBF_TILE
-#define NBF_TILE 384         // ... of the force pass (k_force)
+#define NBF_TILE 544         // ... of the force pass (k_force).  384 (round 2) left the blocks of the fluid's free surface — half-empty
+                             // cells: 256 particles span 128 cells and their full neighbour row holds 516 - 526 — to the general
+                             // kernel's unstaged sweep: 32 blocks per step at 16 M even on the lattice, a ~15 us tail behind the
+                             // lean kernel in every step (force 0.603 -> 0.595 ms at 16 M; more at 1 M and per slab rank)
 #endif
 
 // -------------------------------------------------------------------- density
