@@ -180,6 +180,9 @@ __device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
 #ifndef FS3_STAGE_VEL
 #define FS3_STAGE_VEL 1
 #endif
+#ifndef FS3_CHUNK_BATCH
+#define FS3_CHUNK_BATCH 4    // 32-candidate chunks scanned per walk in the chunked sweep (1: the round-2 form)
+#endif
 #define TILE3_VEL_OFF (TILE3_LDS * 16u)          // bytes from a staged position to the same candidate's velocity
 #define TILE3_FORCE_LDS (TILE3_LDS + (FS3_STAGE_VEL ? 3 * TILE3_ROW : 0))
 typedef unsigned long long u64m;
@@ -646,6 +649,67 @@ __device__ __forceinline__ void sweep3_chunks(const Params3& P, const Tol3& C, c
         const uint32_t hi = r == 0 ? hi0 : r == 1 ? hi1 : hi2;
         const uint32_t b0 = r == 0 ? b00 : r == 1 ? b01 : b02;
         const uint32_t len = hi - lo;
+#if FS3_CHUNK_BATCH > 1
+        // FS3_CHUNK_BATCH chunks of 32 candidates are scanned before the walk starts and their masks are walked as one shift
+        // register (kernels_step.hip force_sweep_chunks: a lane then waits for the wave's slowest lane once per 128
+        // candidates instead of once per 32); the chunks of a batch are consecutive in the row, a refill advances the bases
+#pragma unroll 1
+        for (uint32_t c0 = 0; __any(c0 < len); c0 += 32u * FS3_CHUNK_BATCH) {   // c0 is wave-uniform
+            uint32_t mq[FS3_CHUNK_BATCH];
+            const uint32_t g0 = c0 < len ? lo + c0 : 0u;                 // global index of the batch's first candidate
+            const uint32_t boff0 = (STAGED ? (c0 < len ? (uint32_t)r * TILE3_ROW + (g0 - b0) : 0u) : g0) << 4;
+            const char* src = STAGED ? reinterpret_cast<const char*>(s_flat) : reinterpret_cast<const char*>(pred);
+#define FS3_CAND(off, k) (*reinterpret_cast<const float4*>(src + ((off) + ((k) << 4))))
+#pragma unroll
+            for (int q = 0; q < FS3_CHUNK_BATCH; ++q) {
+                const uint32_t cq = c0 + 32u * (uint32_t)q;
+                const uint32_t clen = cq < len ? (len - cq < 32u ? len - cq : 32u) : 0u;
+                const uint32_t boff = clen ? boff0 + 512u * (uint32_t)q : 0u;
+                uint32_t mask = 0, t = 0;
+                for (; __any(t < clen); t += 4u) {
+                    const float4 q0 = FS3_CAND(boff, t), q1 = FS3_CAND(boff, t + 1u), q2 = FS3_CAND(boff, t + 2u), q3 = FS3_CAND(boff, t + 3u);
+                    const float4 qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
+                        shift_in_not_greater32(mask, ox * ox + oy * oy + oz * oz, lim);
+                    }
+                }
+                mask = t ? mask << (32u - t) : 0u;
+                mask &= clen ? 0xFFFFFFFFu << (32u - clen) : 0u;
+                const uint32_t g = g0 + 32u * (uint32_t)q;
+                if (r == 1 && self_plane && clen && ii - g < clen) mask &= ~(0x80000000u >> (ii - g));   // k != i
+                mq[q] = mask;
+            }
+            uint32_t cur = mq[0], n1 = mq[1 % FS3_CHUNK_BATCH], n2 = FS3_CHUNK_BATCH > 2 ? mq[2 % FS3_CHUNK_BATCH] : 0u,
+                     n3 = FS3_CHUNK_BATCH > 3 ? mq[3 % FS3_CHUNK_BATCH] : 0u;
+            uint32_t boff = boff0, goff = g0 << 4;
+            float4 qn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = qn;
+            bool have = false, pending = false;
+#define FS3_FETCH_NEXT1()                                                                                            \
+    do {                                                                                                             \
+        if (cur == 0u) { cur = n1; n1 = n2; n2 = n3; n3 = 0u; boff += 512u; goff += 512u; }   /* next chunk of the batch */ \
+        have = cur != 0u;                                                                                            \
+        pending = (cur | n1 | n2 | n3) != 0u;            /* an empty chunk in the middle costs this lane one idle trip */ \
+        if (have) {                                                                                                  \
+            const uint32_t tt = (uint32_t)__builtin_clz(cur);                                                        \
+            cur ^= 0x80000000u >> tt;                                                                                \
+            qn = FS3_CAND(boff, tt);                                                                                 \
+            if (STAGED && FS3_STAGE_VEL) vn = *reinterpret_cast<const float4*>(src + (boff + (tt << 4)) + TILE3_VEL_OFF);  \
+            else vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + (goff + (tt << 4)));   \
+        }                                                                                                            \
+    } while (0)
+            FS3_FETCH_NEXT1();
+            while (__any(pending)) {
+                const bool cur_valid = have;
+                const float4 q0 = qn, v0 = vn;
+                FS3_FETCH_NEXT1();
+                if (cur_valid) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A);
+            }
+#undef FS3_FETCH_NEXT1
+#undef FS3_CAND
+        }
+#else
 #pragma unroll 1
         for (uint32_t c0 = 0; __any(c0 < len); c0 += 32u) {              // c0 is wave-uniform
             const uint32_t clen = c0 < len ? (len - c0 < 32u ? len - c0 : 32u) : 0u;
@@ -689,6 +753,7 @@ __device__ __forceinline__ void sweep3_chunks(const Params3& P, const Tol3& C, c
 #undef FS3_FETCH_NEXT1
 #undef FS3_CAND
         }
+#endif
     }
 }
 
