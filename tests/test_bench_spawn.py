@@ -82,3 +82,5 @@ def test_bare_bench_gpus2_runs_to_a_parsed_line():
     assert out["checks"]["particles_conserved"] and out["checks"]["protocol_violations"] == 0
     assert out["roofline"]["bound"] != "hbm" or out["roofline"]["frac"] >= 0.45      # from evidence, not assumed
     assert "rank0_passes_ms" in out["roofline"]
+    # the roofline's kernel is a compute pass; the pack + exchange interval is reported beside it, never as "the kernel"
+    assert not out["roofline"]["kernel"].startswith("predict_key") and out["roofline"]["pack_exchange_ms"] > 0
