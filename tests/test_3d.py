@@ -232,7 +232,8 @@ def test_3d_tolerance_mode_many_steps_stays_close(fs, orc):
 @pytest.mark.gpu
 def test_3d_mask_handoff_does_not_change_a_bit(fs, tmp_path):
     """k3_density hands its nine pass masks to k3_force (default); FS3_HANDOFF=0 makes the force pass scan the 216
-    candidates itself as in round 2, FS3_SEPARATE_KEYGEN=1 brings back the separate predict+key launch.  Same bits."""
+    candidates itself as in round 2, FS3_SEPARATE_KEYGEN=1 brings back the separate predict+key launch, FS3_XCD_CHUNK_LOG2
+    changes the workgroup -> block mapping.  Same bits."""
     import subprocess, sys, textwrap
     prog = textwrap.dedent("""
         import sys, numpy as np
@@ -253,13 +254,17 @@ def test_3d_mask_handoff_does_not_change_a_bit(fs, tmp_path):
         np.save(sys.argv[1], sim.download_particles())
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     outs = []
-    for k, env in enumerate(({}, {"FS3_HANDOFF": "0"}, {"FS3_SEPARATE_KEYGEN": "1"})):
+    # FS3_XCD_CHUNK_LOG2: which workgroup takes which block of particles (XCD-aware mapping) — a permutation of the work
+    for k, env in enumerate(({}, {"FS3_HANDOFF": "0"}, {"FS3_SEPARATE_KEYGEN": "1"}, {"FS3_XCD_CHUNK_LOG2": "0"},
+                             {"FS3_XCD_CHUNK_LOG2": "3", "FS3_HANDOFF": "0"})):
         out = tmp_path / f"o{k}.npy"
         r = subprocess.run([sys.executable, "-c", prog, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
     assert np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8))
     assert np.array_equal(outs[0].view(np.uint8), outs[2].view(np.uint8))
+    assert np.array_equal(outs[0].view(np.uint8), outs[3].view(np.uint8))
+    assert np.array_equal(outs[0].view(np.uint8), outs[4].view(np.uint8))
 
 
 @pytest.mark.parametrize("seed,coincident", [(1, False), (2, True)])

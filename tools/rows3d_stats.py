@@ -48,5 +48,5 @@ for target in steps_list:
     q = np.percentile(ext_max, [50, 90, 99, 100])
     print(f"step {done}: blocks {nb}; row extent per block p50/p90/p99/max = {q}; planes over 400: {unfit_planes} of {3 * nb} "
           f"({100.0 * unfit_planes / (3 * nb):.2f} %); over 384: {int((ext_max > 384).sum())} blocks; "
-          f"waves with a row > 64: {int((wmax > 64).sum())} of {wmax.shape[0]} ({100.0 * (wmax > 64).mean():.2f} %); "
+          f"waves with a row > 64: {int((wmax > 64).sum())} of {wmax.shape[0]} ({100.0 * (wmax > 64).mean():.2f} %), > 128: {100.0 * (wmax > 128).mean():.2f} %, > 192: {100.0 * (wmax > 192).mean():.2f} %; "
           f"max particles per cell {int(cnt.max())}; mean neighbours-in-3x3x3 candidates {float(per_particle.mean()) * 3:.0f}")
