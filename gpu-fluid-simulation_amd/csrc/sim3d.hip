@@ -282,6 +282,47 @@ __device__ __forceinline__ bool plane_masked(const RowRanges& R, bool fit) {
     return fit && !__any(long_row);
 }
 
+// Rows of 65 .. 128 candidates (the compressing column: 5 % of the waves at step 60, 12 - 14 % from step 80 on,
+// tools/rows3d_stats.py): the same hand-off with TWO 64-bit words per row — candidates 0 .. 63 in `hi` (stored in
+// masks[0 .. 9n)), 64 .. 127 in `lo` (masks[9n .. 18n)).  plane_class(): 1 = every row of the wave <= 64 (plane_masked),
+// 2 = every row <= 128, 0 = the chunked sweep.  k3_density and k3_force call it with the same ranges.
+#ifndef FS3_MASK128
+#define FS3_MASK128 1
+#endif
+__device__ __forceinline__ int plane_class(const RowRanges& R, bool fit) {
+    const uint32_t l0 = R.hi[0] - R.lo[0], l1 = R.hi[1] - R.lo[1], l2 = R.hi[2] - R.lo[2];
+    const uint32_t mx = l0 > l1 ? (l0 > l2 ? l0 : l2) : (l1 > l2 ? l1 : l2);
+    if (!fit) return 0;
+    if (!__any(mx > 64u)) return 1;
+    return (FS3_MASK128 && !__any(mx > 128u)) ? 2 : 0;
+}
+// One row of up to 128 candidates into four 32-bit shift registers (t is wave-uniform: the switches are scalar branches).
+__device__ __forceinline__ void scan3_row128(const Params3& P, const float4* base, uint32_t len, float4 me, u64m* hi, u64m* lo) {
+    const float lim = P.h2;
+    uint32_t w0 = 0u, w1 = 0u, w2 = 0u, w3 = 0u, t = 0u;
+#define FS3_SCAN32(W, LIMIT)                                                                                          \
+    for (; t < (LIMIT) && __any(t < len); t += 4u) {                                                                  \
+        const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];                           \
+        const float4 qq[4] = {q0, q1, q2, q3};                                                                        \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                               \
+            const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;                                \
+            shift_in_not_greater32(W, ox * ox + oy * oy + oz * oz, lim);                                              \
+        }                                                                                                             \
+    }
+    FS3_SCAN32(w0, 32u) const uint32_t t0 = t;
+    FS3_SCAN32(w1, 64u) const uint32_t t1 = t;
+    FS3_SCAN32(w2, 96u) const uint32_t t2 = t;
+    FS3_SCAN32(w3, 128u)
+#undef FS3_SCAN32
+    // candidate c of the row sits at bit 31 - (c & 31) of word c / 32: left-align each word by the candidates it took
+    const uint32_t a0 = t0 ? w0 << (32u - t0) : 0u, a1 = t1 > t0 ? w1 << (32u - (t1 - t0)) : 0u;
+    const uint32_t a2 = t2 > t1 ? w2 << (32u - (t2 - t1)) : 0u, a3 = t > t2 ? w3 << (32u - (t - t2)) : 0u;
+    u64m h = ((u64m)a0 << 32) | a1, l = ((u64m)a2 << 32) | a3;
+    h &= len >= 64u ? ~0ull : (len ? ~0ull << (64u - len) : 0ull);
+    l &= len > 64u ? ~0ull << (128u - len) : 0ull;      // len <= 128
+    *hi = h; *lo = l;
+}
+
 __device__ __forceinline__ float dens3_tol(const Params3& P, float4 me, float4 q, float acc) {
     const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
     const float r2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
@@ -306,7 +347,7 @@ template <int MODE>
 __global__ __launch_bounds__(B3F) FS3_DENSITY_ATTR void k3_density(Params3 P, float4* __restrict__ pred, const uint32_t* __restrict__ cs,
                                                  float4* __restrict__ vel_s, u64m* __restrict__ masks,
                                                  const uint32_t* __restrict__ key_s) {
-    __shared__ float4 s_pred[TILE3_LDS];
+    __shared__ float4 s_pred[TILE3_LDS + (FS3_MASK128 ? 64 : 0)];   // a 128-candidate scan reads up to 131 entries from a range start
     __shared__ uint32_t s_red[24];
     uint32_t blk;
     if (!xcd_block3(P, (P.n + B3F - 1) / B3F, &blk)) return;       // uniform
@@ -336,7 +377,32 @@ __global__ __launch_bounds__(B3F) FS3_DENSITY_ATTR void k3_density(Params3 P, fl
             for (int r = 0; r < 3; ++r)
                 for (uint32_t j = threadIdx.x; j < bhi[r] - blo[r]; j += B3F) s_pred[r * TILE3_ROW + j] = pred[blo[r] + j];
             __syncthreads();
-            if (plane_masked(R, fit)) {
+            const int pclass = plane_class(R, fit);
+            if (pclass == 2) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const uint32_t len = R.hi[r] - R.lo[r];
+                    const float4* base = s_pred + ((uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u));
+                    u64m mh, ml;
+                    scan3_row128(P, base, len, me, &mh, &ml);
+                    if (P.handoff && live) {
+                        masks[(size_t)(plane * 3 + r) * P.n + i] = mh;
+                        masks[(size_t)(9 + plane * 3 + r) * P.n + i] = ml;
+                    }
+                    while (mh) {
+                        const uint32_t t = (uint32_t)__builtin_clzll(mh);
+                        mh ^= 0x8000000000000000ull >> t;
+                        if (MODE == 2) rho = dens3_tol(P, me, base[t], rho);
+                        else rho += dens3(P, me, base[t]);
+                    }
+                    while (ml) {
+                        const uint32_t t = (uint32_t)__builtin_clzll(ml);
+                        ml ^= 0x8000000000000000ull >> t;
+                        if (MODE == 2) rho = dens3_tol(P, me, base[64u + t], rho);
+                        else rho += dens3(P, me, base[64u + t]);
+                    }
+                }
+            } else if (pclass == 1) {
                 u64m m[3];
                 uint32_t la[3];
                 scan3_plane<true>(P, R, blo, me, s_pred, m, la);
@@ -549,31 +615,18 @@ __device__ __forceinline__ void pair3_accum(const Params3& P, const Tol3& C, flo
 // 64-bit pass masks, row 0, 1, 2, ascending — the oracle's visiting order.  The masks come from k3_density
 // (Params3::handoff, `masks` != nullptr: three coalesced 8-byte loads) or from a scan of the staged plane.
 // `self_plane`: the lane's own particle sits in row 1 of the middle plane and is skipped (k != i).
+// The walk shared by the 64-bit and the 128-bit mask sweeps: three mask words with the LDS index (and, without the velocity
+// stage, the global index) of their first candidate, consumed in order.
 template <int MODE>
-__device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, const RowRanges& R, const uint32_t* blo, bool self_plane,
-                                             uint32_t ii, float4 me, float4 mv, float pressure,
-                                             const float4* __restrict__ vel_s, const float4* s_flat,
-                                             const u64m* __restrict__ masks, Acc3& A) {
-    u64m m[3];
-    uint32_t la[3];
-    if (masks) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const uint32_t len = R.hi[r] - R.lo[r];
-            la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
-            m[r] = masks[(size_t)r * P.n + ii];                            // all-zero for lanes past the end (never written: masked below)
-            m[r] &= len ? ~0ull << (64u - len) : 0ull;
-        }
-    } else {
-        scan3_plane(P, R, blo, me, s_flat, m, la);
-    }
-    if (self_plane && ii - R.lo[1] < R.hi[1] - R.lo[1]) m[1] &= ~(0x8000000000000000ull >> (ii - R.lo[1]));
+__device__ __forceinline__ void walk3(const Params3& P, const Tol3& C, const u64m* m, const uint32_t* la, const uint32_t* gl,
+                                      float4 me, float4 mv, float pressure, const float4* __restrict__ vel_s,
+                                      const float4* s_flat, Acc3& A) {
     // The three masks are walked as a shift register (round 3): `cur` is the mask being consumed with its LDS / global
     // bases, (n1, n2) wait behind it.  Empty masks are squeezed out first, so "cur == 0 -> pull n1" is all a refill ever
     // needs and the per-neighbour bit extraction touches ONE 64-bit mask and ONE pair of bases (the round-2 form selected
     // among three masks and six bases for every neighbour: ~40 instructions, now ~23).  Row order 0, 1, 2 is kept.
     u64m cur = m[0], n1 = m[1], n2 = m[2];
-    uint32_t lac = la[0] << 4, la_1 = la[1] << 4, la_2 = la[2] << 4, loc = R.lo[0], lo_1 = R.lo[1], lo_2 = R.lo[2];   // la* in bytes
+    uint32_t lac = la[0] << 4, la_1 = la[1] << 4, la_2 = la[2] << 4, loc = gl[0], lo_1 = gl[1], lo_2 = gl[2];   // la* in bytes
     if (n1 == 0ull) { n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }
     if (cur == 0ull) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }
     // Software-pipelined (as in the 2D kernel): the LDS read and the velocity gather of later neighbours are issued
@@ -627,6 +680,65 @@ __device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, co
     }
 #endif
 #undef FS3_FETCH
+}
+
+template <int MODE>
+__device__ __forceinline__ void sweep3_masks(const Params3& P, const Tol3& C, const RowRanges& R, const uint32_t* blo, bool self_plane,
+                                             uint32_t ii, float4 me, float4 mv, float pressure,
+                                             const float4* __restrict__ vel_s, const float4* s_flat,
+                                             const u64m* __restrict__ masks, Acc3& A) {
+    u64m m[3];
+    uint32_t la[3];
+    if (masks) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t len = R.hi[r] - R.lo[r];
+            la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
+            m[r] = masks[(size_t)r * P.n + ii];                            // all-zero for lanes past the end (never written: masked below)
+            m[r] &= len ? ~0ull << (64u - len) : 0ull;
+        }
+    } else {
+        scan3_plane(P, R, blo, me, s_flat, m, la);
+    }
+    if (self_plane && ii - R.lo[1] < R.hi[1] - R.lo[1]) m[1] &= ~(0x8000000000000000ull >> (ii - R.lo[1]));
+    walk3<MODE>(P, C, m, la, R.lo, me, mv, pressure, vel_s, s_flat, A);
+}
+
+// Rows of up to 128 candidates (plane_class() == 2): two words per row, walked as (r0.hi, r0.lo, r1.hi) then (r1.lo, r2.hi,
+// r2.lo) — the same visiting order.  `masks` / `masks_lo`: the plane's words from k3_density, or nullptr (own scan).
+template <int MODE>
+__device__ __forceinline__ void sweep3_masks128(const Params3& P, const Tol3& C, const RowRanges& R, const uint32_t* blo, bool self_plane,
+                                                uint32_t ii, float4 me, float4 mv, float pressure,
+                                                const float4* __restrict__ vel_s, const float4* s_flat,
+                                                const u64m* __restrict__ masks, const u64m* __restrict__ masks_lo, Acc3& A) {
+    u64m mh[3], ml[3];
+    uint32_t la[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t len = R.hi[r] - R.lo[r];
+        la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
+        if (masks) {
+            mh[r] = masks[(size_t)r * P.n + ii] & (len >= 64u ? ~0ull : (len ? ~0ull << (64u - len) : 0ull));
+            ml[r] = masks_lo[(size_t)r * P.n + ii] & (len > 64u ? ~0ull << (128u - len) : 0ull);
+        } else {
+            scan3_row128(P, s_flat + la[r], len, me, &mh[r], &ml[r]);
+        }
+    }
+    if (self_plane && ii - R.lo[1] < R.hi[1] - R.lo[1]) {                  // k != i
+        const uint32_t d = ii - R.lo[1];
+        if (d < 64u) mh[1] &= ~(0x8000000000000000ull >> d);
+        else ml[1] &= ~(0x8000000000000000ull >> (d - 64u));
+    }
+    {
+        const u64m m[3] = {mh[0], ml[0], mh[1]};
+        const uint32_t l[3] = {la[0], la[0] + 64u, la[1]}, g[3] = {R.lo[0], R.lo[0] + 64u, R.lo[1]};
+        walk3<MODE>(P, C, m, l, g, me, mv, pressure, vel_s, s_flat, A);
+    }
+    {
+        const u64m m[3] = {ml[1], mh[2], ml[2]};
+        const uint32_t l[3] = {la[1] + 64u, la[2], la[2] + 64u}, g[3] = {R.lo[1] + 64u, R.lo[2], R.lo[2] + 64u};
+        walk3<MODE>(P, C, m, l, g, me, mv, pressure, vel_s, s_flat, A);
+    }
 }
 
 // General sweep of three rows (one z-plane) for waves that hold a row longer than 64 candidates, or whose
@@ -806,9 +918,14 @@ __device__ __forceinline__ void force3_body(const Params3& P, const float4* __re
                     if (FS3_STAGE_VEL) s_buf[TILE3_LDS + r * TILE3_ROW + j] = vel_s[blo[r] + j];
                 }
             __syncthreads();
-            if (plane_masked(R, fit))     // the same predicate as k3_density: its masks exist exactly for these planes
+            const int pclass = plane_class(R, fit);      // the same predicate as k3_density: its masks exist exactly for these planes
+            if (pclass == 1)
                 sweep3_masks<MODE>(P, C, R, blo, plane == 1, ii, me, mv, pressure, vel_s, s_buf,
                                    masks ? masks + (size_t)plane * 3u * P.n : nullptr, A);
+            else if (pclass == 2)
+                sweep3_masks128<MODE>(P, C, R, blo, plane == 1, ii, me, mv, pressure, vel_s, s_buf,
+                                      masks ? masks + (size_t)plane * 3u * P.n : nullptr,
+                                      masks ? masks + (size_t)(9 + plane * 3) * P.n : nullptr, A);
             else sweep3_chunks<true, MODE>(P, C, R, blo, plane == 1, ii, me, mv, pressure, pred, vel_s, s_buf, A);
         } else {
             sweep3_chunks<false, MODE>(P, C, R, blo, plane == 1, ii, me, mv, pressure, pred, vel_s, s_buf, A);
@@ -1095,7 +1212,7 @@ fs_status fs3_create_ex(const fs3_settings* st, int device, fs_vec3 off, int mat
     T3(s->dirty.alloc(fsd::sort_tile_count((uint32_t)n))); T3(s->work.alloc((size_t)s->work_cap * fsd::gap_entry_size()));
     T3(s->aos.alloc(n));
     s->handoff = !(getenv("FS3_HANDOFF") && atoi(getenv("FS3_HANDOFF")) == 0);
-    if (s->handoff) T3(s->masks.alloc(9 * n));
+    if (s->handoff) T3(s->masks.alloc((FS3_MASK128 ? 18 : 9) * (size_t)n));   // hi words, then the lo words of rows of 65 .. 128
     T3(hipEventCreate(&s->t0)); T3(hipEventCreate(&s->t1));
     T3(hipMemsetAsync(s->cs.p, 0, s->cs.n * 4, s->stream));
     T3(hipMemsetAsync(s->counter.p, 0, 16, s->stream));
