@@ -21,6 +21,7 @@ from ._abi import (  # noqa: F401
     FS_MATH_WGSL_ULP,
     FS_SORT_BITONIC,
     FS_SORT_COUNTING,
+    FS_SLAB_SERIAL,
     PARTICLE3_DTYPE,
     PARTICLE_DTYPE,
     PASS_NAMES,
@@ -366,16 +367,41 @@ class SlabSimulation:
     """
 
     def __init__(self, settings, own_lo, own_hi, has_left, has_right, capacity, recv_capacity, max_cols, device=0,
-                 sort_mode=None):
+                 sort_mode=None, serial=False):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.settings = settings
+        mode = (0 if sort_mode is None else 1 + int(sort_mode)) | (FS_SLAB_SERIAL if serial else 0)
         self.cfg = SlabConfig(int(own_lo), int(own_hi), int(bool(has_left)), int(bool(has_right)), int(capacity),
-                              int(recv_capacity), int(max_cols), 0 if sort_mode is None else 1 + int(sort_mode))
+                              int(recv_capacity), int(max_cols), mode)
         _check(self._lib, self._lib.fs_slab_create(C.byref(settings), int(device), C.byref(self.cfg), C.byref(self._h)))
         self.capacity = int(capacity)
         self.device_index = int(device)
         self.message_bytes = int(self._lib.fs_slab_message_bytes(self._h))
+        # overlapped step (include/fluidsim.h fs_slab_pack): pack() also enqueues the interior columns' whole step,
+        # step() the boundary strips; the exchange in between runs on comm_stream_ptr
+        self.overlapped = bool(self._lib.fs_slab_overlapped(self._h))
+
+    def set_boundary_cols(self, cols):
+        _check(self._lib, self._lib.fs_slab_set_boundary_cols(self._h, int(cols)))
+
+    @property
+    def boundary_cols(self):
+        return int(self._lib.fs_slab_boundary_cols(self._h))
+
+    @property
+    def comm_stream_ptr(self):
+        return self._lib.fs_slab_comm_stream(self._h)
+
+    def comm_begin(self):
+        _check(self._lib, self._lib.fs_slab_comm_begin(self._h))
+
+    def comm_end(self):
+        _check(self._lib, self._lib.fs_slab_comm_end(self._h))
+
+    def wait_packed(self):
+        """Block the host until the outgoing messages of the current pack() are complete."""
+        _check(self._lib, self._lib.fs_slab_wait_packed(self._h))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

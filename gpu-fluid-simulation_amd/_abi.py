@@ -165,7 +165,8 @@ FS_MATH_IEEE = 0
 FS_MATH_WGSL_ULP = 1
 FS_MATH_TOLERANCE = 2
 
-PASS_NAMES = ("predict_key", "sort", "reorder", "density", "force")
+PASS_NAMES = ("predict_key", "sort", "reorder", "density", "force", "boundary")
+FS_SLAB_SERIAL = 0x100
 FS_EXPORT_PARTICLES = 0
 FS_EXPORT_START_INDICES = 1
 
@@ -224,6 +225,13 @@ PROTOTYPES = {
     "fs_slab_message_bytes": (C.c_size_t, [_P]),
     "fs_slab_pack": (C.c_int, [_P, C.POINTER(TickSettings), _P, _P]),
     "fs_slab_step": (C.c_int, [_P, _P, _P]),
+    "fs_slab_overlapped": (C.c_int, [_P]),
+    "fs_slab_set_boundary_cols": (C.c_int, [_P, C.c_uint32]),
+    "fs_slab_boundary_cols": (C.c_uint32, [_P]),
+    "fs_slab_comm_stream": (_P, [_P]),
+    "fs_slab_comm_begin": (C.c_int, [_P]),
+    "fs_slab_comm_end": (C.c_int, [_P]),
+    "fs_slab_wait_packed": (C.c_int, [_P]),
     "fs_slab_counters_read": (C.c_int, [_P, C.POINTER(SlabCounters)]),
     "fs_slab_download": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     "fs_slab_column_histogram": (C.c_int, [_P, _P, C.c_size_t]),
@@ -283,7 +291,7 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fs_abi_version() != 1:
+    if lib.fs_abi_version() != 2:
         raise ExtensionMissing("ABI version mismatch between _abi.py and libfluidsim_hip.so")
     if path is None:
         _lib = lib

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfluidsim_hip.so")
 SOURCES = ["engine.hip", "comm.hip", "buffer.hip", "kernels_step.hip", "kernels_sort.hip", "kernels_slab.hip", "kernels_csort.hip", "kernels_field.hip", "sim3d.hip"]
-HEADERS = ["fs_device.h", "fs_kernels.h", "sort_policy.h", os.path.join("..", "..", "include", "fluidsim.h")]
+HEADERS = ["fs_device.h", "fs_kernels.h", "fs_scan.h", "sort_policy.h", os.path.join("..", "..", "include", "fluidsim.h")]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

@@ -135,7 +135,12 @@ fs_status fs_slab_exchange(fs_sim* sim, fs_comm* comm, int left_rank, int right_
     if (left_rank < 0 && right_rank < 0) return FS_OK;          // a single slab: nothing to exchange
     Rccl* R = rccl();
     if (!R) return comm_fail("librccl not available");
-    hipStream_t st = (hipStream_t)fs_stream(sim);
+    // overlapped step: on the handle's exchange stream, behind the pack (fs_slab_comm_begin) and ahead of the boundary
+    // strips (fs_slab_comm_end) — the interior columns' kernels run beside it on the simulation's stream; serial step: on the
+    // simulation's stream itself
+    const bool overlapped = fs_slab_overlapped(sim) != 0;
+    hipStream_t st = (hipStream_t)(overlapped ? fs_slab_comm_stream(sim) : fs_stream(sim));
+    if (overlapped) { const fs_status r = fs_slab_comm_begin(sim); if (r != FS_OK) return r; }
     nccl_comm c = (nccl_comm)comm;
     // one group: both directions progress together (no send/recv ordering deadlock between neighbours)
     FS_NCCL(R, R->GroupStart());
@@ -151,6 +156,7 @@ fs_status fs_slab_exchange(fs_sim* sim, fs_comm* comm, int left_rank, int right_
     const int rc_end = R->GroupEnd();
     if (rc != NCCL_SUCCESS) return comm_fail(std::string("ncclSend/ncclRecv: ") + R->GetErrorString(rc));
     if (rc_end != NCCL_SUCCESS) return comm_fail(std::string("ncclGroupEnd: ") + R->GetErrorString(rc_end));
+    if (overlapped) return fs_slab_comm_end(sim);
     return FS_OK;
 }
 

@@ -151,6 +151,34 @@ struct fs_sim {
     bool slab_prof = false;                // profiling state latched by fs_slab_pack for the matching fs_slab_step
     uint32_t state_lo = 0, state_hi = 0;   // the owned window the current keys / cell starts were built with
 
+    // Overlapped slab step (counting sort only): fs_slab_pack enqueues the pack AND the whole step of the
+    // interior columns; the halo exchange runs beside it on `comm`; fs_slab_step finishes the columns within `boundary_cols`
+    // of a slab edge on the strip arrays (kernels_slab.hip "boundary strips").
+    bool overlap = false;
+    hipStream_t comm = nullptr;            // the exchange's stream (fs_slab_exchange, or the caller's transport between comm_begin / comm_end)
+    hipEvent_t ev_packed = nullptr;        // main stream: both outgoing messages are complete
+    hipEvent_t ev_exch = nullptr;          // comm stream: both incoming messages have arrived
+    bool exch_pending = false;             // fs_slab_step must wait for ev_exch
+    uint32_t boundary_cols = 4;            // owned columns per neighboured edge left to the strips (>= 3)
+    uint32_t pending_shift = 0;            // columns a window edge moved since the last pack: that step's migrants land deeper
+    uint32_t adv_lo = 0, adv_hi = 0;       // interior columns of the step being enqueued
+    uint32_t strip_win[4] = {0, 0, 0, 0};
+    bool strip_active = false;
+    struct Strip {
+        DevArray<float2> pos, vel, pos_s, vel_s, pred, rho2, pos_out, vel_out;
+        DevArray<float> rho;
+        DevArray<fsd::u64> pairs;
+        DevArray<uint32_t> csort, cs, start_ref, fdefer, fwork, counter, back, rowbase, counters;
+        DevArray<unsigned long long> safe;
+        DevArray<unsigned char> owned;
+        uint32_t cap = 0;
+        void release() {
+            pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho2.release(); pos_out.release();
+            vel_out.release(); rho.release(); pairs.release(); csort.release(); cs.release(); start_ref.release(); fdefer.release();
+            fwork.release(); counter.release(); back.release(); rowbase.release(); counters.release(); safe.release(); owned.release();
+        }
+    } strip;
+
     // Per-pass timing: a ring of event sets recorded on the stream; drained (synchronised
     // and accumulated) only when read or when the ring is full, never per step.
     static const uint32_t PROF_RING = 256;
@@ -166,7 +194,11 @@ struct fs_sim {
         key.release(); safe.release(); fdefer.release(); fwork.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
         owned.release(); blockcnt.release(); stage.release(); msg_state.release(); slab_counters.release();
-        hist.release();
+        hist.release(); strip.release();
+        if (ev_packed) (void)hipEventDestroy(ev_packed);
+        if (ev_exch) (void)hipEventDestroy(ev_exch);
+        if (comm) (void)hipStreamDestroy(comm);
+        comm = nullptr; ev_packed = ev_exch = nullptr;
         for (auto& e : ev) (void)hipEventDestroy(e);
         ev.clear();
         sortp.release();
@@ -290,6 +322,8 @@ fsd::StepParams make_params(const fs_sim& s) {
         P.n = s.capacity;
         P.n_live = s.slab_counters.p;
         P.ref_quirks = 0;   // the global stale-start quirk cannot exist per rank (§8e)
+        // the serial step advances every owned column in its one force launch; the overlapped step narrows this per launch
+        P.adv_lo = P.own_lo; P.adv_hi = P.own_hi; P.adv_outside = 0;
     }
     return P;
 }
@@ -426,10 +460,102 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     if (s->aos_live) s->aos_tick = s->tick;
     if (prof) {
         FS_HIP(hipEventRecord(ev[5], st));
+        FS_HIP(hipEventRecord(ev[6], st));             // FS_PASS_BOUNDARY: slab handles only
         s->prof_pending += 1;
     }
     FS_HIP(s->sortp.step_enqueued(st));
     FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+// ---- overlapped slab step --------------------------------------------------------------------------
+// Step parameters of the two force launches of an overlapped step: the interior launch (main array) and the strip launch.
+fsd::StepParams overlap_params(const fs_sim& s, bool strip) {
+    fsd::StepParams P = make_params(s);
+    P.adv_lo = s.adv_lo; P.adv_hi = s.adv_hi;
+    P.adv_outside = strip ? 1 : 0;
+    if (strip) { P.n = s.strip.cap; P.n_live = s.strip.counters.p; }
+    return P;
+}
+
+// Interior columns and strip windows of the step being packed.  Local columns: 0 and W-1 are padding, 1..2 and W-3..W-2 the
+// ghost columns, own_lo is local column 3 (make_params).
+void plan_overlap(fs_sim* s) {
+    const fs_slab_config& c = s->slab_cfg;
+    const uint32_t z = s->boundary_cols + s->pending_shift;
+    s->pending_shift = 0;
+    const uint32_t width = c.own_hi - c.own_lo, W = width + 6u;
+    const uint32_t zl = c.has_left ? z : 0u, zr = c.has_right ? z : 0u;
+    s->strip_active = c.has_left || c.has_right;
+    s->strip_win[0] = s->strip_win[1] = s->strip_win[2] = s->strip_win[3] = 0u;
+    if (zl + zr >= width) {                        // no interior: the strip holds the whole window
+        s->adv_lo = s->adv_hi = c.own_lo;
+        if (s->strip_active) { s->strip_win[0] = 1u; s->strip_win[1] = W - 1u; }
+        return;
+    }
+    s->adv_lo = c.own_lo + zl; s->adv_hi = c.own_hi - zr;
+    // a window = the two ghost columns + the boundary columns + two columns of interior context
+    const uint32_t lhi = 3u + zl + 2u, rlo = (W - 3u) - zr - 2u;
+    if (c.has_left && c.has_right && lhi >= rlo) { s->strip_win[0] = 1u; s->strip_win[1] = W - 1u; return; }
+    if (c.has_left) { s->strip_win[0] = 1u; s->strip_win[1] = lhi < W - 1u ? lhi : W - 1u; }
+    if (c.has_right) { s->strip_win[2] = rlo > 1u ? rlo : 1u; s->strip_win[3] = W - 1u; }
+}
+
+// Second half of fs_slab_pack: everything that does not need the incoming messages.
+fs_status slab_interior(fs_sim* s) {
+    hipStream_t st = s->stream;
+    FS_HIP(hipEventRecord(s->ev_packed, st));      // the outgoing messages are complete: the exchange may start
+    plan_overlap(s);
+    const fsd::StepParams P = overlap_params(*s, false);
+    hipEvent_t* ev = s->slab_prof ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
+    if (ev) FS_HIP(hipEventRecord(ev[1], st));
+    fsd::launch_counting_sort_pairs(st, s->capacity, P.ncell, s->ncell, s->cs.p, s->csort.p, s->slab_counters.p, s->tick);
+    if (ev) FS_HIP(hipEventRecord(ev[2], st));
+    fsd::launch_counting_reorder_slab(st, P, s->capacity, s->ncell, s->csort.p, s->pairs.p, s->cs.p, s->pos.p, s->vel.p, s->pos_s.p,
+                                      s->vel_s.p, s->pred.p, s->key.p, s->owned.p, s->start_ref.p, s->safe.p, s->fdefer.p,
+                                      s->counter.p + 4);
+    if (s->strip_active) {                          // the main array's share of the strips: also independent of the messages
+        fs_sim::Strip& T = s->strip;
+        fsd::launch_strip_gather(st, P, s->strip_win, s->slab_cfg.recv_capacity, T.cap, s->cs.p, T.rowbase.p, s->pairs.p, s->pos_s.p,
+                                 s->vel_s.p, T.pos.p, T.vel.p, fsd::counting_sort_kt(T.csort.p, T.cap, s->ncell),
+                                 fsd::counting_sort_hist(T.csort.p), T.back.p, T.safe.p, T.counters.p, s->slab_counters.p);
+    }
+    if (ev) FS_HIP(hipEventRecord(ev[3], st));
+    fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
+    if (ev) FS_HIP(hipEventRecord(ev[4], st));
+    fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
+                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
+                      s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint());
+    if (ev) FS_HIP(hipEventRecord(ev[5], st));
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+// fs_slab_step of an overlapped handle: the boundary strips, after the incoming messages.
+fs_status slab_boundary(fs_sim* s, const void* recv_left, const void* recv_right) {
+    hipStream_t st = s->stream;
+    if (s->exch_pending) { FS_HIP(hipStreamWaitEvent(st, s->ev_exch, 0)); s->exch_pending = false; }
+    hipEvent_t* ev = s->slab_prof ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
+    if (s->strip_active) {
+        fs_sim::Strip& T = s->strip;
+        const fsd::StepParams P = overlap_params(*s, false), PS = overlap_params(*s, true);
+        fsd::u64* kt = fsd::counting_sort_kt(T.csort.p, T.cap, s->ncell);
+        fsd::launch_strip_unpack(st, P, s->slab_main, s->slab_cfg.recv_capacity, T.cap, s->slab_cfg.has_left ? recv_left : nullptr,
+                                 s->slab_cfg.has_right ? recv_right : nullptr, T.pos.p, T.vel.p, kt, fsd::counting_sort_hist(T.csort.p),
+                                 T.back.p, T.counters.p, s->slab_counters.p);
+        fsd::launch_counting_sort_pairs(st, T.cap, PS.ncell, s->ncell, T.cs.p, T.csort.p, T.counters.p, s->tick, T.counters.p + 2);
+        fsd::launch_counting_reorder_slab(st, PS, T.cap, s->ncell, T.csort.p, T.pairs.p, T.cs.p, T.pos.p, T.vel.p, T.pos_s.p, T.vel_s.p,
+                                          T.pred.p, (uint32_t*)nullptr, T.owned.p, T.start_ref.p, T.safe.p, T.fdefer.p, T.counter.p + 4,
+                                          T.counters.p + 2);
+        fsd::launch_density(st, PS, T.pred.p, T.cs.p, T.start_ref.p, T.pairs.p, T.safe.p, T.rho.p, T.rho2.p, T.fdefer.p, T.fwork.p, T.counter.p + 4);
+        fsd::launch_force(st, PS, T.pos_s.p, T.vel_s.p, T.pred.p, T.rho2.p, T.cs.p, T.start_ref.p, T.pairs.p, s->tex.p, T.pos_out.p,
+                          T.vel_out.p, T.rho.p, T.fdefer.p, T.fwork.p, T.counter.p + 4, nullptr, nullptr, nullptr, nullptr, 256u, nullptr);
+        fsd::launch_strip_writeback(st, PS, s->slab_main, T.cap, T.pairs.p, T.back.p, T.pos_out.p, T.vel_out.p, T.pred.p, T.rho.p,
+                                    s->pos.p, s->vel.p, s->pred.p, s->rho.p, s->key.p, s->owned.p, s->slab_counters.p);
+    }
+    if (ev) { FS_HIP(hipEventRecord(ev[6], st)); s->prof_pending += 1; }
+    FS_HIP(hipGetLastError());
+    s->slab_packed = false;
     return FS_OK;
 }
 
@@ -562,6 +688,7 @@ fs_status fs_step(fs_sim* s, const fs_tick_settings* t) {
 fs_status fs_sync(fs_sim* s) {
     if (!s) return fail(FS_ERR_INVALID, "null argument");
     FS_HIP(hipStreamSynchronize(s->stream));
+    if (s->comm && s->exch_pending) FS_HIP(hipStreamSynchronize(s->comm));   // an exchange issued but not yet consumed by fs_slab_step
     return FS_OK;
 }
 
@@ -960,7 +1087,11 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     s->opts.ref_quirks = 0;
     // per-rank sorts can only be tolerance-parity with a single-domain run, so slabs
     // default to the O(N) counting sort; cfg->sort_mode = 1 + FS_SORT_BITONIC selects the network
-    s->opts.sort_mode = cfg->sort_mode == 1 + FS_SORT_BITONIC ? FS_SORT_BITONIC : FS_SORT_COUNTING;
+    s->opts.sort_mode = (cfg->sort_mode & 0xFFu) == 1 + FS_SORT_BITONIC ? FS_SORT_BITONIC : FS_SORT_COUNTING;
+    {   // the overlapped step needs the counting sort (ghosts out of the main array); FS_SLAB_SERIAL / FS_SLAB_OVERLAP=0: the serial step
+        const char* e = getenv("FS_SLAB_OVERLAP");
+        s->overlap = s->opts.sort_mode == FS_SORT_COUNTING && !(cfg->sort_mode & FS_SLAB_SERIAL) && !(e && atoi(e) == 0);
+    }
     s->device = device;
     s->slab = true;
     s->slab_cfg = *cfg;
@@ -1011,6 +1142,29 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(s->counter.alloc(8));
     FS_TRY(s->aos.alloc(cap));
     FS_TRY(hipEventCreate(&s->t0)); FS_TRY(hipEventCreate(&s->t1));
+    if (s->overlap) {
+        FS_TRY(hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking));
+        FS_TRY(hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming));
+        FS_TRY(hipEventCreateWithFlags(&s->ev_exch, hipEventDisableTiming));
+        if (const char* e = getenv("FS_SLAB_BOUNDARY_COLS")) s->boundary_cols = (uint32_t)atoi(e) < 3u ? 3u : (uint32_t)atoi(e);
+        // The strip could hold every particle of a narrow slab (all columns within the boundary zone) plus both messages:
+        // same capacity as the main array (memory is not the constraint: ~100 B per slot); its kernels cover the slots in use only.
+        fs_sim::Strip& T = s->strip;
+        T.cap = (uint32_t)cap;
+        FS_TRY(T.pos.alloc(cap)); FS_TRY(T.vel.alloc(cap)); FS_TRY(T.pos_s.alloc(cap)); FS_TRY(T.vel_s.alloc(cap));
+        FS_TRY(T.pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(T.rho2.alloc(cap)); FS_TRY(T.pos_out.alloc(cap)); FS_TRY(T.vel_out.alloc(cap));
+        FS_TRY(T.rho.alloc(cap)); FS_TRY(T.pairs.alloc(cap)); FS_TRY(T.safe.alloc((cap + 63) / 64 + 1)); FS_TRY(T.owned.alloc(cap));
+        FS_TRY(T.fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(T.fwork.alloc(2 * (cap / 256 + 8) + 16));
+        FS_TRY(T.csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
+        FS_TRY(hipMemsetAsync(T.csort.p, 0, T.csort.n * sizeof(uint32_t), s->stream));
+        FS_TRY(T.cs.alloc((size_t)s->ncell + 1)); FS_TRY(T.start_ref.alloc(s->ncell));
+        FS_TRY(T.counter.alloc(8)); FS_TRY(T.counters.alloc(8)); FS_TRY(T.back.alloc(cap)); FS_TRY(T.rowbase.alloc(2 * (size_t)gh + 2));
+        FS_TRY(hipMemsetAsync(T.cs.p, 0, T.cs.n * sizeof(uint32_t), s->stream));
+        FS_TRY(hipMemsetAsync(T.counter.p, 0, 8 * sizeof(uint32_t), s->stream));
+        FS_TRY(hipMemsetAsync(T.counters.p, 0, 8 * sizeof(uint32_t), s->stream));
+        FS_TRY(hipMemsetAsync(T.pred.p, 0, (cap + FS_PRED_SLACK) * sizeof(float2), s->stream));
+        FS_TRY(hipMemsetAsync(T.pairs.p, 0xFF, cap * sizeof(fsd::u64), s->stream));
+    }
     FS_TRY(hipMemsetAsync(s->start_ref.p, 0, s->start_ref.n * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->cs.p, 0, s->cs.n * sizeof(uint32_t), s->stream));
     if (s->tex.n) FS_TRY(hipMemsetAsync(s->tex.p, 0, s->tex.n * sizeof(float2), s->stream));
@@ -1052,8 +1206,56 @@ fs_status fs_slab_set_window(fs_sim* s, uint32_t own_lo, uint32_t own_hi) {
     if (own_lo >= own_hi || own_hi > s->grid_w || own_hi - own_lo < 4 || own_hi - own_lo > s->slab_cfg.max_cols)
         return fail(FS_ERR_INVALID, "bad owned window");
     if (s->slab_packed) return fail(FS_ERR_INVALID, "window change between pack and step");
+    {   // the particles of a column that changes hands arrive at the new owner as migrants, that many columns deeper than usual:
+        // the next (overlapped) step widens its boundary zone by the shift
+        const uint32_t dl = s->slab_cfg.has_left ? (own_lo > s->slab_cfg.own_lo ? own_lo - s->slab_cfg.own_lo : s->slab_cfg.own_lo - own_lo) : 0u;
+        const uint32_t dr = s->slab_cfg.has_right ? (own_hi > s->slab_cfg.own_hi ? own_hi - s->slab_cfg.own_hi : s->slab_cfg.own_hi - own_hi) : 0u;
+        const uint32_t d = dl > dr ? dl : dr;
+        if (d > s->pending_shift) s->pending_shift = d;
+    }
     s->slab_cfg.own_lo = own_lo;
     s->slab_cfg.own_hi = own_hi;
+    return FS_OK;
+}
+
+/* Overlapped step: owned columns per neighboured slab edge that are left to the boundary strips (computed AFTER the halo
+ * exchange; everything farther inside runs while the messages are in flight).  A migrant must land at least 3 columns short of
+ * the interior — cols >= 3 + the columns the fastest particle crosses in one step; violations are counted in far_halo. */
+fs_status fs_slab_set_boundary_cols(fs_sim* s, uint32_t cols) {
+    if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
+    if (s->slab_packed) return fail(FS_ERR_INVALID, "boundary change between pack and step");
+    s->boundary_cols = cols < 3u ? 3u : cols;
+    return FS_OK;
+}
+uint32_t fs_slab_boundary_cols(const fs_sim* s) { return (s && s->slab && s->overlap) ? s->boundary_cols : 0u; }
+int fs_slab_overlapped(const fs_sim* s) { return (s && s->slab && s->overlap) ? 1 : 0; }
+void* fs_slab_comm_stream(const fs_sim* s) { return (s && s->slab) ? (void*)s->comm : nullptr; }
+
+/* Transport hooks of the overlapped step (a no-op on a serial handle, whose exchange is ordered by the simulation's stream):
+ * fs_slab_comm_begin makes the exchange stream wait for the packed messages, the caller then issues its send/recv ON
+ * fs_slab_comm_stream(), fs_slab_comm_end records their completion for fs_slab_step to wait on.  fs_slab_exchange does all
+ * three itself.  fs_slab_wait_packed blocks the HOST until the outgoing messages are complete (host-staged transports). */
+fs_status fs_slab_comm_begin(fs_sim* s) {
+    if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
+    if (!s->overlap) return FS_OK;
+    FS_HIP(hipSetDevice(s->device));
+    if (!s->slab_packed) FS_HIP(hipEventRecord(s->ev_packed, s->stream));   // outside a step: behind whatever the simulation's stream holds
+    FS_HIP(hipStreamWaitEvent(s->comm, s->ev_packed, 0));
+    return FS_OK;
+}
+fs_status fs_slab_comm_end(fs_sim* s) {
+    if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
+    if (!s->overlap) return FS_OK;
+    FS_HIP(hipSetDevice(s->device));
+    FS_HIP(hipEventRecord(s->ev_exch, s->comm));
+    s->exch_pending = true;
+    return FS_OK;
+}
+fs_status fs_slab_wait_packed(fs_sim* s) {
+    if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
+    FS_HIP(hipSetDevice(s->device));
+    if (s->overlap && s->slab_packed) FS_HIP(hipEventSynchronize(s->ev_packed));
+    else FS_HIP(hipStreamSynchronize(s->stream));
     return FS_OK;
 }
 
@@ -1083,10 +1285,12 @@ fs_status fs_slab_pack(fs_sim* s, const fs_tick_settings* t, void* send_left, vo
                           counting ? fsd::counting_sort_kt(s->csort.p, s->capacity, s->ncell) : s->pairs.p,
                           fsd::counting_sort_hist(s->csort.p), s->blockcnt.p, s->stage.p, s->msg_state.p, s->tick,
                           s->slab_cfg.has_left ? send_left : nullptr,
-                          s->slab_cfg.has_right ? send_right : nullptr, s->slab_counters.p, s->counter.p, s->safe.p, counting);
+                          s->slab_cfg.has_right ? send_right : nullptr, s->slab_counters.p, s->counter.p, s->safe.p, counting,
+                          s->overlap);
     FS_HIP(hipGetLastError());
     s->slab_packed = true;
     s->state_lo = s->slab_cfg.own_lo; s->state_hi = s->slab_cfg.own_hi;
+    if (s->overlap) return slab_interior(s);
     return FS_OK;
 }
 
@@ -1096,6 +1300,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     if ((s->slab_cfg.has_left && !recv_left) || (s->slab_cfg.has_right && !recv_right))
         return fail(FS_ERR_INVALID, "missing incoming message buffer");
     FS_HIP(hipSetDevice(s->device));
+    if (s->overlap) return slab_boundary(s, recv_left, recv_right);
     const fsd::StepParams P = make_params(*s);
     hipStream_t st = s->stream;
     hipEvent_t* ev = s->slab_prof ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
@@ -1127,7 +1332,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
                       s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint());
-    if (ev) { FS_HIP(hipEventRecord(ev[5], st)); s->prof_pending += 1; }
+    if (ev) { FS_HIP(hipEventRecord(ev[5], st)); FS_HIP(hipEventRecord(ev[6], st)); s->prof_pending += 1; }
     FS_HIP(hipGetLastError());
     s->slab_packed = false;
     return FS_OK;
@@ -1149,7 +1354,8 @@ fs_status fs_slab_max_speed(fs_sim* s, float* out) {
     FS_HIP(hipSetDevice(s->device));
     uint32_t bits = 0;
     FS_HIP(hipMemsetAsync(s->slab_counters.p + 5, 0, sizeof(uint32_t), s->stream));
-    fsd::launch_slab_maxspeed(s->stream, s->slab_counters.p, s->vel.p, s->owned.p, s->slab_counters.p + 5);
+    fsd::launch_slab_maxspeed(s->stream, s->slab_counters.p, s->vel.p, s->owned.p, s->slab_counters.p + 5,
+                              s->slab_main, s->overlap ? 2u * s->slab_cfg.recv_capacity : 0u);
     FS_HIP(hipMemcpyAsync(&bits, s->slab_counters.p + 5, sizeof bits, hipMemcpyDeviceToHost, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));
     std::memcpy(out, &bits, sizeof bits);
@@ -1166,9 +1372,10 @@ fs_status fs_slab_rebalance_stats(fs_sim* s, uint32_t* stats_dev, uint32_t* hist
     FS_HIP(hipSetDevice(s->device));
     const fsd::StepParams P = make_params_of_state(*s);
     FS_HIP(hipMemsetAsync(hist_dev, 0, grid_w_global * sizeof(uint32_t), s->stream));
-    fsd::launch_slab_colhist(s->stream, P, s->cs.p, hist_dev);
+    const uint32_t migr = s->overlap ? 2u * s->slab_cfg.recv_capacity : 0u;     // overlapped step: last step's migrants sit past the main slots
+    fsd::launch_slab_colhist(s->stream, P, s->cs.p, hist_dev, s->slab_main, migr, s->owned.p, s->key.p);
     FS_HIP(hipMemsetAsync(s->slab_counters.p + 5, 0, sizeof(uint32_t), s->stream));
-    fsd::launch_slab_maxspeed(s->stream, s->slab_counters.p, s->vel.p, s->owned.p, s->slab_counters.p + 5);
+    fsd::launch_slab_maxspeed(s->stream, s->slab_counters.p, s->vel.p, s->owned.p, s->slab_counters.p + 5, s->slab_main, migr);
     // counters [2] lost, [3] overflow, [4] far_halo, [5] max-speed bits are adjacent
     FS_HIP(hipMemcpyAsync(stats_dev, s->slab_counters.p + 2, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
     FS_HIP(hipGetLastError());
@@ -1183,13 +1390,20 @@ fs_status fs_slab_download(fs_sim* s, fs_particle* dst, uint8_t* owned, size_t c
     FS_HIP(hipMemcpyAsync(&nl, s->slab_counters.p, sizeof nl, hipMemcpyDeviceToHost, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));
     if (nl > s->capacity) nl = s->capacity;
-    *n_live = nl;
+    // overlapped step: the sorted prefix [0, nl) (owned + this rank's near-leavers) and, past the main slots, the 2R slots
+    // that mirror the incoming messages — the migrants among them carry the owned flag; returned back to back
+    const size_t migr = s->overlap ? 2u * (size_t)s->slab_cfg.recv_capacity : 0u;
+    if (s->overlap && nl > s->slab_main) nl = s->slab_main;
     const size_t n = nl < cap ? nl : cap;
-    if (n == 0) return FS_OK;
+    const size_t m = cap - n < migr ? cap - n : migr;
+    *n_live = (uint32_t)(n + m);
+    if (n + m == 0) return FS_OK;
     // before the first step the state lives in pos/vel (import); afterwards pos/vel hold the advanced state
-    fsd::launch_slab_export(s->stream, P, (uint32_t)n, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p, s->aos.p);
-    FS_HIP(hipMemcpyAsync(dst, s->aos.p, n * sizeof(fs_particle), hipMemcpyDeviceToHost, s->stream));
-    FS_HIP(hipMemcpyAsync(owned, s->owned.p, n, hipMemcpyDeviceToHost, s->stream));
+    fsd::launch_slab_export(s->stream, P, s->capacity, s->pos.p, s->pred.p, s->vel.p, s->rho.p, s->key.p, s->aos.p);
+    if (n) FS_HIP(hipMemcpyAsync(dst, s->aos.p, n * sizeof(fs_particle), hipMemcpyDeviceToHost, s->stream));
+    if (n) FS_HIP(hipMemcpyAsync(owned, s->owned.p, n, hipMemcpyDeviceToHost, s->stream));
+    if (m) FS_HIP(hipMemcpyAsync(dst + n, s->aos.p + s->slab_main, m * sizeof(fs_particle), hipMemcpyDeviceToHost, s->stream));
+    if (m) FS_HIP(hipMemcpyAsync(owned + n, s->owned.p + s->slab_main, m, hipMemcpyDeviceToHost, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));
     return FS_OK;
 }
@@ -1199,7 +1413,8 @@ fs_status fs_slab_column_histogram(fs_sim* s, uint32_t* hist, size_t grid_w_glob
     FS_HIP(hipSetDevice(s->device));
     const fsd::StepParams P = make_params_of_state(*s);
     FS_HIP(hipMemsetAsync(s->hist.p, 0, s->hist.n * sizeof(uint32_t), s->stream));
-    fsd::launch_slab_colhist(s->stream, P, s->cs.p, s->hist.p);
+    fsd::launch_slab_colhist(s->stream, P, s->cs.p, s->hist.p, s->slab_main, s->overlap ? 2u * s->slab_cfg.recv_capacity : 0u,
+                             s->owned.p, s->key.p);
     std::vector<uint32_t> tmp(s->grid_w);
     FS_HIP(hipMemcpyAsync(tmp.data(), s->hist.p, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));

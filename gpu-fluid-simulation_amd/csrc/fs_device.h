@@ -50,7 +50,21 @@ struct StepParams {
     uint32_t own_lo, own_hi;   // owned window [own_lo, own_hi) in GLOBAL columns
     uint32_t grid_w_global;
     const uint32_t* n_live;    // device-side live count (slab mode); nullptr -> n
+    // --- slab mode, overlapped step (engine.hip fs_slab_pack / fs_slab_step): which owned columns THIS launch of the force
+    // pass advances.  adv_outside == 0: the columns [adv_lo, adv_hi) (the interior, computed while the halo messages are in
+    // flight; the serial step passes the whole owned window); adv_outside == 1: the owned columns OUTSIDE [adv_lo, adv_hi)
+    // (the boundary strips, computed after the unpack).  Global columns, own_lo <= adv_lo <= adv_hi <= own_hi.
+    uint32_t adv_lo, adv_hi;
+    int32_t adv_outside;
 };
+
+// Slab mode: does the force pass of this launch advance a particle whose GLOBAL cell column is cg?  (Ghosts — columns outside
+// the owned window — are never advanced.)
+__device__ __forceinline__ bool slab_advances(const StepParams& P, int32_t cg) {
+    const bool in_adv = cg >= (int32_t)P.adv_lo && cg < (int32_t)P.adv_hi;
+    const bool in_own = cg >= (int32_t)P.own_lo && cg < (int32_t)P.own_hi;
+    return P.adv_outside ? (in_own && !in_adv) : in_adv;
+}
 
 #define FS_DEAD_KEY 0xFFFFFFFFu   // slot holds no particle (slab mode); sorts to the end
 

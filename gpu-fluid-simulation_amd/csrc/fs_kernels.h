@@ -59,7 +59,21 @@ void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, 
                       int has_right, const float2* pos, const float2* vel, const unsigned char* owned, u64* out,
                       uint32_t* hist, void* blockcnt, uint32_t* stage, void* state, uint32_t epoch,
                       void* msg_left, void* msg_right, uint32_t* counters, uint32_t* gap_counter, unsigned long long* safe,
-                      bool counting);
+                      bool counting, bool overlap = false /* the slots past main_slots hold last step's migrants (overlapped step) */);
+// Overlapped slab step — the boundary strips (kernels_slab.hip).  `P` = the main array's StepParams; win[4] = the two strip
+// windows as LOCAL column ranges [win[0], win[1]) and [win[2], win[3]); strip_counters: [0] live strip particles (written by the
+// strip's scan), [1] slots filled from the main array, [2] slots in use.
+void launch_strip_gather(hipStream_t st, const StepParams& P, const uint32_t win[4], uint32_t R, uint32_t strip_cap,
+                         const uint32_t* cs, uint32_t* rowbase /* 2 * grid_h */, const u64* pairs, const float2* pos_s,
+                         const float2* vel_s, float2* sp_pos, float2* sp_vel, u64* kt, uint32_t* hist, uint32_t* back,
+                         unsigned long long* safe, uint32_t* strip_counters, uint32_t* counters);
+void launch_strip_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, uint32_t strip_cap,
+                         const void* msg_left, const void* msg_right, float2* sp_pos, float2* sp_vel, u64* kt, uint32_t* hist,
+                         uint32_t* back, const uint32_t* strip_counters, uint32_t* counters);
+void launch_strip_writeback(hipStream_t st, const StepParams& P_strip, uint32_t main_slots, uint32_t strip_cap, const u64* sp_pairs,
+                            const uint32_t* back, const float2* sp_pos_out, const float2* sp_vel_out, const float2* sp_pred,
+                            const float* sp_rho, float2* pos, float2* vel, float2* pred, float* rho, uint32_t* key,
+                            unsigned char* owned, uint32_t* counters);
 size_t slab_stage_words(uint32_t cap);
 size_t slab_msg_groups(uint32_t cap);
 void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, const void* msg_left,
@@ -74,9 +88,11 @@ void launch_slab_export(hipStream_t st, const StepParams& P, uint32_t cap, const
                         const float2* vel, const float* rho, const uint32_t* key, void* out);
 void launch_slab_import(hipStream_t st, const StepParams& P, uint32_t n, uint32_t cap, const void* in, float2* pos,
                         float2* pred, float2* vel, float* rho, uint32_t* key, unsigned char* owned);
-void launch_slab_colhist(hipStream_t st, const StepParams& P, const uint32_t* cs, uint32_t* hist_global);
+// migr_first / migr_count: the migrant slots of an overlapped step (outside the sorted prefix), or 0 / 0
+void launch_slab_colhist(hipStream_t st, const StepParams& P, const uint32_t* cs, uint32_t* hist_global, uint32_t migr_first = 0,
+                         uint32_t migr_count = 0, const unsigned char* owned = nullptr, const uint32_t* key = nullptr);
 void launch_slab_maxspeed(hipStream_t st, const uint32_t* n_live, const float2* vel, const unsigned char* owned,
-                          uint32_t* out_bits);
+                          uint32_t* out_bits, uint32_t migr_first = 0, uint32_t migr_count = 0);
 size_t slab_message_bytes(uint32_t R);
 
 // Bitonic network of sort.wgsl:27-51 / simulation.rs:323-347 on (key<<32 | index) pairs.
@@ -119,11 +135,13 @@ void launch_counting_reorder(hipStream_t st, const StepParams& P, uint32_t* scra
                              const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s,
                              uint32_t* key_s, uint32_t* start_ref, unsigned long long* safe, uint32_t* force_defer,
                              uint32_t* force_work_count);
+// n_dev (may be null): device word holding the number of slots in use (<= cap); the grids still cover `cap`
 void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, uint32_t ncell_alloc, uint32_t* cs, uint32_t* scratch,
-                                uint32_t* n_live_out, uint32_t epoch);
+                                uint32_t* n_live_out, uint32_t epoch, const uint32_t* n_dev = nullptr);
 void launch_counting_reorder_slab(hipStream_t st, const StepParams& P, uint32_t cap, uint32_t ncell_alloc, uint32_t* scratch, u64* pairs,
                                   const uint32_t* cs, const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s,
                                   float2* pred_s, uint32_t* key_s, unsigned char* owned, uint32_t* start_ref,
-                                  unsigned long long* safe, uint32_t* force_defer, uint32_t* force_work_count);
+                                  unsigned long long* safe, uint32_t* force_defer, uint32_t* force_work_count,
+                                  const uint32_t* n_dev = nullptr);
 
 }  // namespace fsd

@@ -124,8 +124,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_lookback(uint32_t* __restri
 // Four slots per thread, 256 apart: the three dependent loads of a slot (kt -> cs -> store address) of all four are in flight
 // together (the kernel is latency-bound at a slab rank's size).
 #define SC_ITEMS 4
+// n_dev (may be null): a device-side slot count below `n` (the boundary strips of an overlapped slab step use a prefix of their
+// slot array whose length only the device knows); the grid still covers `n`.
 __global__ __launch_bounds__(CS_BLOCK) void k_cs_scatter(uint32_t n, uint32_t ncell, const u64* __restrict__ kt,
-                                                         const uint32_t* __restrict__ cs, uint32_t* __restrict__ slot_src) {
+                                                         const uint32_t* __restrict__ cs, uint32_t* __restrict__ slot_src,
+                                                         const uint32_t* __restrict__ n_dev) {
+    if (n_dev) { const uint32_t m = *n_dev; n = m < n ? m : n; }
+    if (blockIdx.x * (CS_BLOCK * SC_ITEMS) >= n) return;
     const uint32_t i0 = blockIdx.x * (CS_BLOCK * SC_ITEMS) + threadIdx.x;
     u64 e[SC_ITEMS];
 #pragma unroll
@@ -155,8 +160,10 @@ __global__ __launch_bounds__(CS_BLOCK) void k_cs_fixreorder(StepParams P, uint32
                                                             float2* __restrict__ pred_s, uint32_t* __restrict__ key_s,
                                                             unsigned char* __restrict__ owned, uint32_t* __restrict__ start_ref,
                                                             unsigned long long* __restrict__ safe, uint32_t* __restrict__ force_defer,
-                                                            uint32_t* __restrict__ force_work_count) {
+                                                            uint32_t* __restrict__ force_work_count,
+                                                            const uint32_t* __restrict__ n_dev) {
     const uint32_t p = blockIdx.x * CS_BLOCK + threadIdx.x;
+    if (n_dev) { const uint32_t m = *n_dev; n = m < n ? m : n; }     // device-side slot count (see k_cs_scatter)
     if (threadIdx.x == 0) {                      // the force pass's worklists of this step (same block size and count)
         force_defer[2u * blockIdx.x] = 0u;
         force_defer[2u * blockIdx.x + 1u] = 0u;
@@ -218,19 +225,22 @@ uint32_t* counting_sort_hist(uint32_t* scratch) { return scratch; }
 
 // Slab mode: kt / hist were filled by k_slab_pack + k_slab_unpack (kernels_slab.hip).
 void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, uint32_t ncell_alloc, uint32_t* cs, uint32_t* scratch,
-                                uint32_t* n_live_out, uint32_t epoch) {
+                                uint32_t* n_live_out, uint32_t epoch, const uint32_t* n_dev) {
     const CsLayout L = cs_layout(scratch, cap, ncell_alloc);
     const uint32_t count = ncell + 1u, tiles = (count + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_scan_lookback, dim3(tiles), dim3(SCAN_BLOCK), 0, st, L.hist, count, cs, L.state, L.ticket, epoch, n_live_out);
-    hipLaunchKernelGGL(k_cs_scatter, dim3((cap + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), dim3(CS_BLOCK), 0, st, cap, ncell, L.kt, cs, L.slot_src);
+    hipLaunchKernelGGL(k_cs_scatter, dim3((cap + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), dim3(CS_BLOCK), 0, st, cap, ncell, L.kt, cs, L.slot_src, n_dev);
 }
+uint32_t* counting_sort_slot_src(uint32_t* scratch, uint32_t n, uint32_t ncell_alloc) { return cs_layout(scratch, n, ncell_alloc).slot_src; }
 void launch_counting_reorder_slab(hipStream_t st, const StepParams& P, uint32_t cap, uint32_t ncell_alloc, uint32_t* scratch, u64* pairs,
                                   const uint32_t* cs, const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s,
                                   float2* pred_s, uint32_t* key_s, unsigned char* owned, uint32_t* start_ref,
-                                  unsigned long long* safe, uint32_t* force_defer, uint32_t* force_work_count) {
+                                  unsigned long long* safe, uint32_t* force_defer, uint32_t* force_work_count,
+                                  const uint32_t* n_dev) {
     const CsLayout L = cs_layout(scratch, cap, ncell_alloc);
     hipLaunchKernelGGL(k_cs_fixreorder<true>, dim3((cap + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, P, cap, L.kt, cs,
-                       L.slot_src, pairs, pos_in, vel_in, pos_s, vel_s, pred_s, key_s, owned, start_ref, safe, force_defer, force_work_count);
+                       L.slot_src, pairs, pos_in, vel_in, pos_s, vel_s, pred_s, key_s, owned, start_ref, safe, force_defer, force_work_count,
+                       n_dev);
 }
 
 void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos, const float2* vel, uint32_t* cs,
@@ -241,7 +251,7 @@ void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos
     hipLaunchKernelGGL(k_cs_hist, grid, block, 0, st, P, pos, vel, L.kt, L.hist, gap_counter, safe);
     hipLaunchKernelGGL(k_scan_lookback, dim3((count + SCAN_TILE - 1) / SCAN_TILE), dim3(SCAN_BLOCK), 0, st, L.hist, count, cs, L.state, L.ticket,
                        epoch, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_cs_scatter, dim3((n + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), block, 0, st, n, ncell, L.kt, cs, L.slot_src);
+    hipLaunchKernelGGL(k_cs_scatter, dim3((n + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), block, 0, st, n, ncell, L.kt, cs, L.slot_src, (const uint32_t*)nullptr);
 }
 void launch_counting_reorder(hipStream_t st, const StepParams& P, uint32_t* scratch, u64* pairs, const uint32_t* cs,
                              const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s,
@@ -250,7 +260,7 @@ void launch_counting_reorder(hipStream_t st, const StepParams& P, uint32_t* scra
     const CsLayout L = cs_layout(scratch, P.n, P.ncell);
     hipLaunchKernelGGL(k_cs_fixreorder<false>, dim3((P.n + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, P, P.n, L.kt, cs,
                        L.slot_src, pairs, pos_in, vel_in, pos_s, vel_s, pred_s, key_s, (unsigned char*)nullptr, start_ref, safe,
-                       force_defer, force_work_count);
+                       force_defer, force_work_count, (const uint32_t*)nullptr);
 }
 
 }  // namespace fsd

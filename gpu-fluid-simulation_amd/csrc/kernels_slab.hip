@@ -48,8 +48,11 @@ struct SlabHeader { uint32_t count, overflow, pad0, pad1; };
 //               fixed-size messages in SLOT ORDER (deterministic); the last workgroup writes the two headers.
 // (A look-back over the 256-slot blocks themselves — one launch — was measured first: its prefix frontier advances ~128
 //  blocks per global-memory round trip, 0.17 ms for the 11 136 blocks of an 8-way rank.  The chain must be short.)
+// overlap != 0 (the overlapped step, engine.hip): ghosts never enter the main array, so the slots past `main_slots` are not the
+// unpack area of this step but hold the MIGRANTS the boundary strips received and advanced in the last one (owned flag
+// set by k_strip_writeback); they are carried over like the sorted prefix.
 template <bool COUNTING>
-__global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t cap, uint32_t main_slots,
+__global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t cap, uint32_t main_slots, int overlap,
                                                         int has_left, int has_right, const float2* __restrict__ pos,
                                                         const float2* __restrict__ vel,
                                                         const unsigned char* __restrict__ owned, u64* __restrict__ out /* kt or pairs */,
@@ -64,8 +67,9 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t c
     const uint32_t n_prev = *P.n_live;
     unsigned char f = 0;
     uint32_t key = FS_DEAD_KEY;
-    if (i < main_slots) {
-        if (i < n_prev && owned[i]) {
+    if (overlap && i == 0 && n_prev > main_slots) atomicAdd(&counters[3], 1u);   // the sorted prefix ran into the migrant slots
+    if (i < main_slots || (overlap && i < cap)) {
+        if ((i < main_slots ? i < n_prev : true) && owned[i]) {
             const float2 pr = predict_pos(P, pos[i], vel[i]);
             uint32_t cxg;
             key = slab_key(P, pr, &cxg);
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t c
         uint32_t base = 0;
         if (r.is_head) base = atomicAdd(&hist[k], r.length);
         base = __shfl(base, r.head_lane);
-        if (i < main_slots) out[i] = ((u64)key << 32) | (u64)(active ? base + r.offset : 0u);
+        if (i < main_slots || (overlap && i < cap)) out[i] = ((u64)key << 32) | (u64)(active ? base + r.offset : 0u);
     }
     // ---- the slots each message needs, listed per block in slot order
     const unsigned long long mL = __ballot(f & 1), mR = __ballot(f & 2);
@@ -344,7 +348,22 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_colhist(StepParams P, const u
     if (cg < (int32_t)P.own_lo || cg >= (int32_t)P.own_hi) return;
     uint32_t sum = 0;
     for (uint32_t y = 0; y < P.grid_h; ++y) sum += cs[y * P.grid_w + c + 1] - cs[y * P.grid_w + c];
-    hist_global[cg] = sum;
+    atomicAdd(&hist_global[cg], sum);       // (the buffer was zeroed; k_slab_colhist_migrants adds to the same words)
+}
+
+// Overlapped step: the migrants a rank received and advanced in the last step sit in the slots past the main ones, outside
+// the sorted prefix and its cell table; `key` holds their local cell key of that step.
+__global__ __launch_bounds__(SL_BLOCK) void k_slab_colhist_migrants(StepParams P, uint32_t first, uint32_t count,
+                                                                    const unsigned char* __restrict__ owned,
+                                                                    const uint32_t* __restrict__ key,
+                                                                    uint32_t* __restrict__ hist_global) {
+    const uint32_t j = blockIdx.x * SL_BLOCK + threadIdx.x;
+    if (j >= count || !owned[first + j]) return;
+    const uint32_t k = key[first + j];
+    if (k == FS_DEAD_KEY) return;
+    const uint32_t cy = k / P.grid_w;
+    const int32_t cg = (int32_t)(k - cy * P.grid_w) + P.col_origin;
+    if (cg >= 0 && cg < (int32_t)P.grid_w_global) atomicAdd(&hist_global[cg], 1u);
 }
 
 // Largest |velocity| among the owned live particles, as f32 bits (non-negative floats order like their bits):
@@ -352,10 +371,14 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_colhist(StepParams P, const u
 __global__ __launch_bounds__(SL_BLOCK) void k_slab_maxspeed(const uint32_t* __restrict__ n_live,
                                                             const float2* __restrict__ vel,
                                                             const unsigned char* __restrict__ owned,
-                                                            uint32_t* __restrict__ out_bits) {
+                                                            uint32_t* __restrict__ out_bits, uint32_t migr_first,
+                                                            uint32_t migr_count) {
     const uint32_t n = *n_live;
     float m = 0.0f;
-    for (uint32_t i = blockIdx.x * SL_BLOCK + threadIdx.x; i < n; i += gridDim.x * SL_BLOCK) {
+    // the sorted prefix [0, n), then (overlapped step) the migrant slots [migr_first, migr_first + migr_count)
+    for (uint32_t t = blockIdx.x * SL_BLOCK + threadIdx.x; t < n + migr_count; t += gridDim.x * SL_BLOCK) {
+        const uint32_t i = t < n ? t : migr_first + (t - n);
+        if (t >= n && i < n) continue;                       // (a prefix that ran into the migrant slots: counted once)
         if (!owned[i]) continue;
         const float2 v = vel[i];
         const float sp = sqrt_rn(v.x * v.x + v.y * v.y);
@@ -366,19 +389,201 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_maxspeed(const uint32_t* __re
     if ((threadIdx.x & 63u) == 0 && m > 0.0f) atomicMax(out_bits, __float_as_uint(m));
 }
 
+// ------------------------------------------------------------------ overlapped step: the boundary strips
+// (engine.hip fs_slab_pack / fs_slab_step.)  Ghosts stay OUT of the main sorted array.  While the two halo messages are in
+// flight the rank sorts its carried-over particles and runs density + force for the INTERIOR columns [adv_lo, adv_hi); what
+// the received records can influence — the owned columns within `Z` of a slab edge — is computed afterwards on a small second
+// array, the STRIP: every particle of the main array whose cell column lies in a strip window (the two ghost columns, the
+// boundary columns, and two columns of interior context), plus the received records.  The strip uses the main array's own
+// window and cell keys, is counting-sorted like it, and goes through the SAME k_density / k_force (StepParams::adv_outside);
+// k_strip_writeback puts the results back: boundary particles to their index in the main arrays, migrants to the slot past
+// the main ones that mirrors their position in the message (k_slab_pack carries them over in the next step).
+//
+//   k_strip_rows      (1 workgroup) per grid row and window: the main array's index range -> exclusive offsets; totals
+//   k_strip_gather    one wave per (row, window): copies {pos, vel} of the range into the strip's slots, histogram + ticket
+//   k_strip_unpack    the received records behind them; classification (ghost / migrant), protocol checks
+//   k_strip_writeback results -> main arrays
+struct StripWin { uint32_t lo0, hi0, lo1, hi1; };      // LOCAL columns [lo0, hi0) and [lo1, hi1); an empty window has lo == hi
+#define STRIP_NONE 0xFFFFFFFFu
+
+#define SR_BLOCK 1024
+__global__ __launch_bounds__(SR_BLOCK) void k_strip_rows(uint32_t grid_w, uint32_t grid_h, StripWin W, uint32_t R2,
+                                                         const uint32_t* __restrict__ cs, uint32_t* __restrict__ rowbase,
+                                                         uint32_t* __restrict__ strip_counters) {
+    __shared__ uint32_t s_wave[SR_BLOCK / 64];
+    __shared__ uint32_t s_carry;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    const uint32_t entries = 2u * grid_h;
+    for (uint32_t e0 = 0; e0 < entries; e0 += SR_BLOCK) {
+        const uint32_t e = e0 + threadIdx.x;
+        uint32_t c = 0;
+        if (e < entries) {
+            const uint32_t y = e >> 1, lo = (e & 1u) ? W.lo1 : W.lo0, hi = (e & 1u) ? W.hi1 : W.hi0;
+            if (lo < hi) c = cs[y * grid_w + hi] - cs[y * grid_w + lo];
+        }
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
+        if (lane == 63u) s_wave[w] = inc;
+        __syncthreads();
+        uint32_t off = s_carry, tot = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < SR_BLOCK / 64; ++k) { const uint32_t t = s_wave[k]; if (k < w) off += t; tot += t; }
+        if (e < entries) rowbase[e] = off + inc - c;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        strip_counters[1] = s_carry;                 // slots filled from the main array
+        strip_counters[2] = s_carry + R2;            // slots in use once the received records sit behind them
+    }
+}
+
+__global__ __launch_bounds__(SL_BLOCK) void k_strip_gather(uint32_t grid_w, uint32_t grid_h, uint32_t ncell, StripWin W,
+                                                           uint32_t strip_cap, const uint32_t* __restrict__ cs,
+                                                           const uint32_t* __restrict__ rowbase, const u64* __restrict__ pairs,
+                                                           const float2* __restrict__ pos_s, const float2* __restrict__ vel_s,
+                                                           float2* __restrict__ sp_pos, float2* __restrict__ sp_vel,
+                                                           u64* __restrict__ kt, uint32_t* __restrict__ hist,
+                                                           uint32_t* __restrict__ back, unsigned long long* __restrict__ safe,
+                                                           uint32_t* __restrict__ counters) {
+    {   // the strip's safe-operand words (k_cs_fixreorder clears the unsafe bits)
+        const uint32_t words = (strip_cap + 63u) / 64u;
+        for (uint32_t t = blockIdx.x * SL_BLOCK + threadIdx.x; t < words; t += gridDim.x * SL_BLOCK) safe[t] = ~0ull;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t e = blockIdx.x * (SL_BLOCK / 64) + (threadIdx.x >> 6);       // wave-uniform
+    if (e >= 2u * grid_h) return;
+    const uint32_t y = e >> 1, lo = (e & 1u) ? W.lo1 : W.lo0, hi = (e & 1u) ? W.hi1 : W.hi0;
+    if (lo >= hi) return;
+    const uint32_t a = cs[y * grid_w + lo], c = cs[y * grid_w + hi] - a, base = rowbase[e];
+    for (uint32_t k0 = 0; k0 < c; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        const bool active = k < c && base + k < strip_cap;
+        if (k < c && !active) atomicAdd(&counters[3], 1u);           // strip capacity exceeded (never: it equals the main array's)
+        uint32_t key = 0;
+        if (active) key = (uint32_t)(pairs[a + k] >> 32);
+        const uint32_t kc = key < ncell ? key : ncell - 1u;
+        const WaveRun r = wave_run(kc, active);
+        uint32_t t = 0;
+        if (r.is_head) t = atomicAdd(&hist[kc], r.length);
+        t = __shfl(t, r.head_lane);
+        if (active) {
+            const uint32_t slot = base + k;
+            kt[slot] = ((u64)key << 32) | (u64)(t + r.offset);
+            sp_pos[slot] = pos_s[a + k];
+            sp_vel[slot] = vel_s[a + k];
+            back[slot] = a + k;                      // the main arrays' sorted index: where the force pass writes
+        }
+    }
+}
+
+// Received records -> strip slots [n_sm + j]; `P` is the MAIN array's StepParams (same window, same keys).
+__global__ __launch_bounds__(SL_BLOCK) void k_strip_unpack(StepParams P, uint32_t main_slots, uint32_t R, uint32_t strip_cap,
+                                                           const SlabHeader* __restrict__ hdr_left,
+                                                           const float4* __restrict__ rec_left,
+                                                           const SlabHeader* __restrict__ hdr_right,
+                                                           const float4* __restrict__ rec_right,
+                                                           float2* __restrict__ sp_pos, float2* __restrict__ sp_vel,
+                                                           u64* __restrict__ kt, uint32_t* __restrict__ hist,
+                                                           uint32_t* __restrict__ back,
+                                                           const uint32_t* __restrict__ strip_counters,
+                                                           uint32_t* __restrict__ counters) {
+    const uint32_t j = blockIdx.x * SL_BLOCK + threadIdx.x;
+    const bool in_range = j < 2u * R;
+    const bool right = j >= R;
+    const uint32_t jj = right ? j - R : j;
+    const SlabHeader* hdr = right ? hdr_right : hdr_left;
+    const float4* rec = right ? rec_right : rec_left;
+    uint32_t cnt = 0;
+    if (in_range && hdr) { cnt = hdr->count < R ? hdr->count : R; if (jj == 0 && hdr->overflow) atomicAdd(&counters[3], 1u); }
+    const uint32_t slot = strip_counters[1] + j;
+    const bool room = slot < strip_cap;
+    uint32_t key = FS_DEAD_KEY, dst = STRIP_NONE;
+    if (in_range && jj < cnt) {
+        if (!room) {
+            atomicAdd(&counters[3], 1u);
+        } else {
+            const float4 r = rec[jj];
+            const float2 p = make_float2(r.x, r.y), v = make_float2(r.z, r.w);
+            sp_pos[slot] = p;
+            sp_vel[slot] = v;
+            uint32_t cxg;
+            key = slab_key(P, predict_pos(P, p, v), &cxg);
+            if (key == FS_DEAD_KEY) atomicAdd(&counters[2], 1u);           // travelled farther than slab + halo
+            // a migrant that lands in my FAR halo zone would have been needed by my other neighbour too
+            if (!right && cxg + 2u >= P.own_hi && cxg < P.own_hi) atomicAdd(&counters[4], 1u);
+            if (right && cxg < P.own_lo + 2u && cxg >= P.own_lo) atomicAdd(&counters[4], 1u);
+            // ... and one that lands within 2 columns of the interior (or in it) was not seen by the interior launch, which
+            // ran while this message was in flight: the boundary zone was too narrow for its speed (fs_slab_set_boundary_cols)
+            if (key != FS_DEAD_KEY && P.adv_lo < P.adv_hi) {
+                if (!right && cxg + 2u >= P.adv_lo) atomicAdd(&counters[4], 1u);
+                if (right && cxg < P.adv_hi + 2u) atomicAdd(&counters[4], 1u);
+            }
+            if (key != FS_DEAD_KEY && cxg >= P.own_lo && cxg < P.own_hi) dst = main_slots + j;   // a migrant: mine from now on
+        }
+    }
+    const bool active = key != FS_DEAD_KEY;
+    const uint32_t k = key < P.ncell ? key : P.ncell - 1u;
+    const WaveRun r = wave_run(k, active);
+    uint32_t base = 0;
+    if (r.is_head) base = atomicAdd(&hist[k], r.length);
+    base = __shfl(base, r.head_lane);
+    if (in_range && room) {
+        kt[slot] = ((u64)key << 32) | (u64)(active ? base + r.offset : 0u);
+        back[slot] = dst;
+    }
+}
+
+// Results of the strip's force pass -> the main arrays.  `P` = the strip's StepParams (adv_outside = 1).
+__global__ __launch_bounds__(SL_BLOCK) void k_strip_writeback(StepParams P, uint32_t main_slots, const u64* __restrict__ sp_pairs,
+                                                              const uint32_t* __restrict__ back,
+                                                              const float2* __restrict__ sp_pos_out,
+                                                              const float2* __restrict__ sp_vel_out,
+                                                              const float2* __restrict__ sp_pred, const float* __restrict__ sp_rho,
+                                                              float2* __restrict__ pos, float2* __restrict__ vel,
+                                                              float2* __restrict__ pred, float* __restrict__ rho,
+                                                              uint32_t* __restrict__ key, unsigned char* __restrict__ owned,
+                                                              uint32_t* __restrict__ counters) {
+    const uint32_t i = blockIdx.x * SL_BLOCK + threadIdx.x;
+    if (i >= *P.n_live) return;
+    const u64 pr = sp_pairs[i];
+    const uint32_t k = (uint32_t)(pr >> 32), dst = back[(uint32_t)pr];
+    if (dst == STRIP_NONE || k == FS_DEAD_KEY) return;     // a ghost record
+    const uint32_t cy = k / P.grid_w;
+    const int32_t cg = (int32_t)(k - cy * P.grid_w) + P.col_origin;
+    if (!slab_advances(P, cg)) {
+        // interior context (advanced by the interior launch) — or a migrant that landed beyond the boundary zone: nobody
+        // advanced it, it is lost (k_strip_unpack has counted it in far_halo already)
+        if (dst >= main_slots) atomicAdd(&counters[2], 1u);
+        return;
+    }
+    pos[dst] = sp_pos_out[i];
+    vel[dst] = sp_vel_out[i];
+    rho[dst] = sp_rho[i];
+    if (dst >= main_slots) {                               // a migrant: the rest of its record, and it is carried over from now on
+        pred[dst] = sp_pred[i];
+        key[dst] = k;
+        owned[dst] = 1;
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 static inline uint32_t nb(uint32_t n) { return (n + SL_BLOCK - 1) / SL_BLOCK; }
 
 void launch_slab_maxspeed(hipStream_t st, const uint32_t* n_live, const float2* vel, const unsigned char* owned,
-                          uint32_t* out_bits) {
-    hipLaunchKernelGGL(k_slab_maxspeed, dim3(1024), dim3(SL_BLOCK), 0, st, n_live, vel, owned, out_bits);
+                          uint32_t* out_bits, uint32_t migr_first, uint32_t migr_count) {
+    hipLaunchKernelGGL(k_slab_maxspeed, dim3(1024), dim3(SL_BLOCK), 0, st, n_live, vel, owned, out_bits, migr_first, migr_count);
 }
 
 void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, int has_left,
                       int has_right, const float2* pos, const float2* vel, const unsigned char* owned, u64* out,
                       uint32_t* hist, void* blockcnt, uint32_t* stage /* 2 x capacity words */, void* state, uint32_t epoch,
                       void* msg_left, void* msg_right, uint32_t* counters, uint32_t* gap_counter, unsigned long long* safe,
-                      bool counting) {
+                      bool counting, bool overlap) {
     // covers ALL slots (P.n = capacity): slots past `main_slots` only check for stranded owned particles
     const uint32_t cap = P.n > main_slots ? P.n : main_slots;
     const uint32_t blocks = nb(cap), groups = (blocks + MSG_GROUP - 1u) / MSG_GROUP;
@@ -387,10 +592,10 @@ void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, 
     SlabHeader* hl = (SlabHeader*)msg_left;
     SlabHeader* hr = (SlabHeader*)msg_right;
     if (counting)
-        hipLaunchKernelGGL(k_slab_pack<true>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, has_left, has_right, pos,
+        hipLaunchKernelGGL(k_slab_pack<true>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, overlap ? 1 : 0, has_left, has_right, pos,
                            vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe);
     else
-        hipLaunchKernelGGL(k_slab_pack<false>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, has_left, has_right, pos,
+        hipLaunchKernelGGL(k_slab_pack<false>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, 0, has_left, has_right, pos,
                            vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe);
     if (!hl && !hr) return;                                             // no neighbour: nothing to send
     hipLaunchKernelGGL(k_slab_msg, dim3(groups), dim3(SL_BLOCK), 0, st, blocks, R, (const uint2*)blockcnt, stage_l, stage_r, pos,
@@ -439,10 +644,44 @@ void launch_slab_import(hipStream_t st, const StepParams& P, uint32_t n, uint32_
                        pred, vel, rho, key, owned);
 }
 
-void launch_slab_colhist(hipStream_t st, const StepParams& P, const uint32_t* cs, uint32_t* hist_global) {
+void launch_slab_colhist(hipStream_t st, const StepParams& P, const uint32_t* cs, uint32_t* hist_global, uint32_t migr_first,
+                         uint32_t migr_count, const unsigned char* owned, const uint32_t* key) {
     hipLaunchKernelGGL(k_slab_colhist, dim3(nb(P.grid_w)), dim3(SL_BLOCK), 0, st, P, cs, hist_global);
+    if (migr_count)
+        hipLaunchKernelGGL(k_slab_colhist_migrants, dim3(nb(migr_count)), dim3(SL_BLOCK), 0, st, P, migr_first, migr_count, owned, key,
+                           hist_global);
 }
 
 size_t slab_message_bytes(uint32_t R) { return sizeof(SlabHeader) + (size_t)R * sizeof(float4); }
+
+// ---- overlapped step: the boundary strips
+void launch_strip_gather(hipStream_t st, const StepParams& P, const uint32_t win[4], uint32_t R, uint32_t strip_cap,
+                         const uint32_t* cs, uint32_t* rowbase, const u64* pairs, const float2* pos_s, const float2* vel_s,
+                         float2* sp_pos, float2* sp_vel, u64* kt, uint32_t* hist, uint32_t* back, unsigned long long* safe,
+                         uint32_t* strip_counters, uint32_t* counters) {
+    const StripWin W{win[0], win[1], win[2], win[3]};
+    hipLaunchKernelGGL(k_strip_rows, dim3(1), dim3(SR_BLOCK), 0, st, P.grid_w, P.grid_h, W, 2u * R, cs, rowbase, strip_counters);
+    const uint32_t waves = 2u * P.grid_h, per_block = SL_BLOCK / 64;
+    hipLaunchKernelGGL(k_strip_gather, dim3((waves + per_block - 1) / per_block), dim3(SL_BLOCK), 0, st, P.grid_w, P.grid_h, P.ncell,
+                       W, strip_cap, cs, rowbase, pairs, pos_s, vel_s, sp_pos, sp_vel, kt, hist, back, safe, counters);
+}
+
+void launch_strip_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, uint32_t strip_cap,
+                         const void* msg_left, const void* msg_right, float2* sp_pos, float2* sp_vel, u64* kt, uint32_t* hist,
+                         uint32_t* back, const uint32_t* strip_counters, uint32_t* counters) {
+    const SlabHeader* hl = (const SlabHeader*)msg_left;
+    const SlabHeader* hr = (const SlabHeader*)msg_right;
+    hipLaunchKernelGGL(k_strip_unpack, dim3(nb(2 * R)), dim3(SL_BLOCK), 0, st, P, main_slots, R, strip_cap, hl,
+                       hl ? (const float4*)(hl + 1) : nullptr, hr, hr ? (const float4*)(hr + 1) : nullptr, sp_pos, sp_vel, kt, hist,
+                       back, strip_counters, counters);
+}
+
+void launch_strip_writeback(hipStream_t st, const StepParams& P_strip, uint32_t main_slots, uint32_t strip_cap, const u64* sp_pairs,
+                            const uint32_t* back, const float2* sp_pos_out, const float2* sp_vel_out, const float2* sp_pred,
+                            const float* sp_rho, float2* pos, float2* vel, float2* pred, float* rho, uint32_t* key,
+                            unsigned char* owned, uint32_t* counters) {
+    hipLaunchKernelGGL(k_strip_writeback, dim3(nb(strip_cap)), dim3(SL_BLOCK), 0, st, P_strip, main_slots, sp_pairs, back, sp_pos_out,
+                       sp_vel_out, sp_pred, sp_rho, pos, vel, pred, rho, key, owned, counters);
+}
 
 }  // namespace fsd

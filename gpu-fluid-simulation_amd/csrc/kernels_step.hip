@@ -755,9 +755,9 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
     A.seed = ii * 12u + P.frame_time * 69u;                             // compute.wgsl:161
     uint32_t cx, cy;
     xy_local(P, me, &cx, &cy);
-    if (P.n_live) {   // slab mode: ghosts (outside the owned columns) are not advanced
-        const int32_t cg = (int32_t)cx + P.col_origin;
-        if (cg < (int32_t)P.own_lo || cg >= (int32_t)P.own_hi) live = false;
+    if (P.n_live) {   // slab mode: ghosts (outside the owned columns) are not advanced, and an overlapped step splits the owned
+                      // columns between the interior launch and the boundary-strip launch (fs_device.h slab_advances)
+        if (!slab_advances(P, (int32_t)cx + P.col_origin)) live = false;
     }
     RowRanges R;
 #pragma unroll

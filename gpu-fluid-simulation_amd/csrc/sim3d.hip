@@ -1160,7 +1160,7 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     if (tol) hipLaunchKernelGGL(k3_force<2>, gridf, blockf, 0, st, P, s->pos.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos_s.p, s->vel.p, fm, s->key.p, s->pairs.p);
     else hipLaunchKernelGGL(k3_force<0>, gridf, blockf, 0, st, P, s->pos.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos_s.p, s->vel.p, fm, s->key.p, s->pairs.p);
     { float4* t = s->pos.p; s->pos.p = s->pos_s.p; s->pos_s.p = t; }
-    if (ev) { H3(hipEventRecord(ev[5], st)); s->pending += 1; }
+    if (ev) { H3(hipEventRecord(ev[5], st)); H3(hipEventRecord(ev[6], st)); /* FS_PASS_BOUNDARY: slab handles only */ s->pending += 1; }
     H3(s->sortp.step_enqueued(st));
     H3(hipGetLastError());
     return FS_OK;

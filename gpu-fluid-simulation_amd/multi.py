@@ -90,6 +90,14 @@ def default_trim_margin():
 SPEED_CLAMP = 500.0          # compute.wgsl:118-122: |v| <= 500 after every step
 
 
+def boundary_columns(vmax, accel, dt, h, steps, safety=1.5, floor=4):
+    """Width of the boundary zone of an overlapped slab step (fs_slab_set_boundary_cols): a migrant must land at least 3
+    columns short of the interior, so 3 + the columns the fastest particle can cross in ONE step at any time before the next
+    re-balancing step (`steps` steps away; vmax = largest speed now, all ranks).  Never below `floor`."""
+    v_end = min(SPEED_CLAMP, safety * float(vmax) + float(accel) * float(dt) * steps)
+    return max(int(floor), 3 + int(np.ceil(v_end * float(dt) / float(h))))
+
+
 def travel_margin(vmax, accel, dt, h, steps, safety=1.5):
     """Columns a particle can cross in `steps` steps: it moves at most (safety * vmax + accel * dt * k) * dt in
     step k (vmax = largest speed now, all ranks; accel = |gravity|, the one body force; `safety` covers pressure
@@ -223,9 +231,29 @@ class HipSlabEngine:
     def pack(self, tick):
         self.sim.pack(tick, self._ptr("send_left"), self._ptr("send_right"))
         if not self.cuda:       # stage device -> host tensors for gloo
-            self.sim.sync()
+            self.sim.wait_packed()      # the messages only: an overlapped handle goes on computing its interior columns
             for k in ("send_left", "send_right"):
                 getattr(self.t, k).numpy()[:] = self.dev[k].read()
+
+    def exchange(self):
+        """The neighbour exchange of this step.  Overlapped handle + device transport: issued on the handle's exchange stream
+        (behind the pack, beside the interior columns' kernels); fs_slab_step waits for it."""
+        t = self.t
+        if not self.sim.overlapped or not self.cuda or isinstance(t, NativeTransport):
+            t.exchange()        # host transport / serial handle / fs_slab_exchange (which does the stream hand-over itself)
+            return
+        if not t.ops:
+            return
+        if getattr(self, "_comm_ext", None) is None:
+            self._comm_ext = t.torch.cuda.ExternalStream(self.sim.comm_stream_ptr, device=t.device)
+        self.sim.comm_begin()
+        with t.torch.cuda.stream(self._comm_ext):
+            t.exchange()
+        self.sim.comm_end()
+
+    def set_boundary_cols(self, cols):
+        if self.sim.overlapped:
+            self.sim.set_boundary_cols(cols)
 
     def finish(self):
         if not self.cuda:
@@ -314,12 +342,25 @@ class SlabDriver:
         self.next_rebalance = rebalance_every
         self.last_margin = self.trim_margin
         self.tick = None
+        self.initial_vmax = 0.0                    # largest speed of the initial state (callers that start with moving particles set it)
+        self.last_boundary = None
+
+    def _set_boundary(self, vmax, interval):
+        """Overlapped engines: size the boundary zone for the speeds expected until the next re-balancing step."""
+        if not hasattr(self.e, "set_boundary_cols") or self.tick is None:
+            return
+        g = self.tick.gravity
+        cols = boundary_columns(vmax, float(np.hypot(g.x, g.y)), self.tick.delta, self._h(), interval)
+        self.last_boundary = cols
+        self.e.set_boundary_cols(cols)
 
     def step(self, tick):
         self.tick = tick
-        self.e.pack(tick)
-        self.t.exchange()
-        self.e.finish()
+        if self.steps == 0:
+            self._set_boundary(self.initial_vmax, self.rebalance_every or 64)
+        self.e.pack(tick)           # overlapped engine: the pack AND everything that needs no incoming message
+        (getattr(self.e, "exchange", None) or self.t.exchange)()
+        self.e.finish()             # overlapped engine: the boundary strips
         self.steps += 1
         if self.rebalance_every and self.steps >= self.next_rebalance:
             self.rebalance()
@@ -340,6 +381,7 @@ class SlabDriver:
             hist, stats = self.e.rebalance_inputs(self.grid_w)
             if not self.check_counters:
                 stats[:3] = 0
+            c = {"max over ranks": [int(x) for x in stats[:3]]}
         else:
             hist = self.e.column_histogram(self.grid_w).astype(np.int64)
             hist = self._allreduce(hist, dist.ReduceOp.SUM)          # tiny (grid_w * 8 B), every K steps only
@@ -369,6 +411,7 @@ class SlabDriver:
             accel = float(np.hypot(g.x, g.y))
             margin = max(margin, travel_margin(stats[3], accel, self.tick.delta, self._h(), interval))
         self.last_margin = margin
+        self._set_boundary(stats[3], interval)
         new = trim_outer_edges(new, hist, margin)               # outer edges follow the occupied columns
         if self.max_cols:                                       # never wider than the engine's tables
             new[0] = max(new[0], new[1] - self.max_cols)

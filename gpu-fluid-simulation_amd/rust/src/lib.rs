@@ -102,7 +102,9 @@ const _: () = assert!(std::mem::size_of::<Particle3>() == 48);
 #[repr(C)] pub struct fs_buffer { _p: [u8; 0] }
 #[repr(C)] pub struct fs_comm { _p: [u8; 0] }
 
-pub const PASS_COUNT: usize = 5;
+pub const PASS_COUNT: usize = 6;   // FS_PASS_COUNT (the sixth, FS_PASS_BOUNDARY, is non-zero on slab handles only)
+/// fs_slab_config.sort_mode | SLAB_SERIAL: the serial slab step instead of the overlapped one.
+pub const SLAB_SERIAL: u32 = 0x100;
 pub const COMM_ID_BYTES: usize = 128;
 
 // Every entry point of include/fluidsim.h, in the header's order.
@@ -150,6 +152,13 @@ extern "C" {
     fn fs_slab_message_bytes(sim: *const fs_sim) -> usize;
     fn fs_slab_pack(sim: *mut fs_sim, tick: *const TickSettings, send_left: *mut c_void, send_right: *mut c_void) -> c_int;
     fn fs_slab_step(sim: *mut fs_sim, recv_left: *const c_void, recv_right: *const c_void) -> c_int;
+    fn fs_slab_overlapped(sim: *const fs_sim) -> c_int;
+    fn fs_slab_set_boundary_cols(sim: *mut fs_sim, cols: u32) -> c_int;
+    fn fs_slab_boundary_cols(sim: *const fs_sim) -> u32;
+    fn fs_slab_comm_stream(sim: *const fs_sim) -> *mut c_void;
+    fn fs_slab_comm_begin(sim: *mut fs_sim) -> c_int;
+    fn fs_slab_comm_end(sim: *mut fs_sim) -> c_int;
+    fn fs_slab_wait_packed(sim: *mut fs_sim) -> c_int;
     fn fs_slab_counters_read(sim: *mut fs_sim, out: *mut SlabCounters) -> c_int;
     fn fs_slab_download(sim: *mut fs_sim, dst: *mut ParticleInstance, owned: *mut u8, cap: usize, n_live: *mut u32) -> c_int;
     fn fs_slab_max_speed(sim: *mut fs_sim, out: *mut f32) -> c_int;
@@ -382,6 +391,15 @@ impl SlabSimulation {
     pub fn message_bytes(&self) -> usize { unsafe { fs_slab_message_bytes(self.raw) } }
     pub unsafe fn pack(&mut self, tick: &TickSettings, send_left: *mut c_void, send_right: *mut c_void) { check(fs_slab_pack(self.raw, tick, send_left, send_right)); }
     pub unsafe fn step(&mut self, recv_left: *const c_void, recv_right: *const c_void) { check(fs_slab_step(self.raw, recv_left, recv_right)); }
+    /// Overlapped step (the default with the counting sort): `pack` also enqueues the interior columns' whole step, `step` the
+    /// boundary strips; the exchange between them runs on `comm_stream()` (Comm::exchange does the hand-over itself).
+    pub fn overlapped(&self) -> bool { unsafe { fs_slab_overlapped(self.raw) != 0 } }
+    pub fn set_boundary_cols(&mut self, cols: u32) { check(unsafe { fs_slab_set_boundary_cols(self.raw, cols) }); }
+    pub fn boundary_cols(&self) -> u32 { unsafe { fs_slab_boundary_cols(self.raw) } }
+    pub fn comm_stream(&self) -> *mut c_void { unsafe { fs_slab_comm_stream(self.raw) } }
+    pub fn comm_begin(&mut self) { check(unsafe { fs_slab_comm_begin(self.raw) }); }
+    pub fn comm_end(&mut self) { check(unsafe { fs_slab_comm_end(self.raw) }); }
+    pub fn wait_packed(&mut self) { check(unsafe { fs_slab_wait_packed(self.raw) }); }
     pub fn counters(&mut self) -> SlabCounters { let mut c = SlabCounters::default(); check(unsafe { fs_slab_counters_read(self.raw, &mut c) }); c }
     pub fn max_speed(&mut self) -> f32 { let mut v = 0f32; check(unsafe { fs_slab_max_speed(self.raw, &mut v) }); v }
     pub fn column_histogram(&mut self, hist: &mut [u32]) { check(unsafe { fs_slab_column_histogram(self.raw, hist.as_mut_ptr(), hist.len()) }); }

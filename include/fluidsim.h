@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 1
+#define FS_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ status */
 typedef enum fs_status {
@@ -258,8 +258,10 @@ fs_status fs_render_density(fs_sim* sim, const fs_view* view, float* rgba_host);
 
 /* -------------------------------------------------------------- profiling */
 /* Per-pass device time measured with hipEvents on the simulation's stream. */
+/* FS_PASS_BOUNDARY: slab handles only — the part of a step that runs after the halo exchange (overlapped step: waiting for
+ * the incoming messages + the boundary strips); 0 on every other handle. */
 enum { FS_PASS_PREDICT_KEY = 0, FS_PASS_SORT = 1, FS_PASS_REORDER = 2, FS_PASS_DENSITY = 3,
-       FS_PASS_FORCE = 4, FS_PASS_COUNT = 5 };
+       FS_PASS_FORCE = 4, FS_PASS_BOUNDARY = 5, FS_PASS_COUNT = 6 };
 fs_status fs_profile_enable(fs_sim* sim, int enable);
 /* Accumulated milliseconds per pass since the last reset and number of steps. */
 fs_status fs_profile_read(fs_sim* sim, double ms[FS_PASS_COUNT], uint64_t* steps, int reset);
@@ -279,15 +281,19 @@ typedef struct fs_slab_config {
     uint32_t capacity;            /* particle slots of the local array (incl. 2*recv_capacity) */
     uint32_t recv_capacity;       /* records per incoming message */
     uint32_t max_cols;            /* widest owned window this handle must support (re-balancing) */
-    uint32_t sort_mode;           /* 0 = default (counting sort); 1 + fs_sort_mode selects explicitly */
+    uint32_t sort_mode;           /* low byte: 0 = default (counting sort), 1 + fs_sort_mode selects explicitly; | FS_SLAB_SERIAL:
+                                     the serial step (pack -> exchange -> everything) instead of the overlapped one */
 } fs_slab_config;
+#define FS_SLAB_SERIAL 0x100u
 
 typedef struct fs_slab_counters {
-    uint32_t n_live;        /* live slots after the last step (owned + ghosts) */
+    uint32_t n_live;        /* live slots after the last step (owned + ghosts; overlapped step: the sorted prefix, i.e. the
+                               carried-over particles — ghosts and this step's migrants live outside it) */
     uint32_t lost;          /* particles that left slab + halo in one step (must stay 0) */
     uint32_t overflow;      /* message capacity exceeded, or owned particles stranded past the main slots
                                (n_live > capacity - 2*recv_capacity at the next pack); must stay 0 */
-    uint32_t far_halo;      /* migrants that landed in the receiver's far halo zone (must stay 0) */
+    uint32_t far_halo;      /* migrants that landed in the receiver's far halo zone, or (overlapped step) within 2 columns
+                               of its interior: the boundary zone was too narrow for their speed (must stay 0) */
 } fs_slab_counters;
 
 fs_status fs_slab_create(const fs_settings* global_settings, int device, const fs_slab_config* cfg, fs_sim** out);
@@ -297,10 +303,29 @@ fs_status fs_slab_upload_owned(fs_sim* sim, const fs_particle* src, size_t n);
  * fs_slab_column_histogram still describe the stored state in the window it was built with. */
 fs_status fs_slab_set_window(fs_sim* sim, uint32_t own_lo, uint32_t own_hi);
 size_t fs_slab_message_bytes(const fs_sim* sim);
-/* Begin a step: predict, classify, fill the two outgoing device messages (NULL = no neighbour). */
+/* Begin a step: predict, classify, fill the two outgoing device messages (NULL = no neighbour).
+ * OVERLAPPED step (the default with the counting sort; fs_slab_overlapped() == 1): ghosts never enter the rank's sorted
+ * array, so the call goes on to enqueue everything that does not need the incoming messages — sort and reorder of the
+ * carried-over particles, density, and the force pass of the INTERIOR columns (farther than the boundary zone from a
+ * neighboured edge) — behind the pack, and the exchange runs beside that on a second stream.  fs_slab_step then finishes
+ * the boundary columns on a small second array ("strip": ghost + boundary + 2 context columns and the received records). */
 fs_status fs_slab_pack(fs_sim* sim, const fs_tick_settings* tick, void* send_left, void* send_right);
 /* Finish the step with the two incoming device messages (NULL = no neighbour). */
 fs_status fs_slab_step(fs_sim* sim, const void* recv_left, const void* recv_right);
+/* Overlapped step: 1 / 0; owned columns per neighboured edge left to the strips (default 4, at least 3; set it to
+ * 3 + the columns the fastest particle can cross in one step — a migrant that lands closer than 3 columns to the interior
+ * is counted in fs_slab_counters.far_halo; a window edge moved by fs_slab_set_window widens the next step's zone by itself). */
+int fs_slab_overlapped(const fs_sim* sim);
+fs_status fs_slab_set_boundary_cols(fs_sim* sim, uint32_t cols);
+uint32_t fs_slab_boundary_cols(const fs_sim* sim);
+/* Transport hooks of the overlapped step (no-ops on a serial handle, where the simulation's own stream orders the exchange):
+ * fs_slab_comm_begin makes fs_slab_comm_stream() wait for the packed messages; the caller issues its send / recv on THAT
+ * stream; fs_slab_comm_end records their completion, which the next fs_slab_step waits for.  fs_slab_exchange does all three.
+ * fs_slab_wait_packed blocks the host until the outgoing messages are complete (transports that stage through the host). */
+void* fs_slab_comm_stream(const fs_sim* sim);
+fs_status fs_slab_comm_begin(fs_sim* sim);
+fs_status fs_slab_comm_end(fs_sim* sim);
+fs_status fs_slab_wait_packed(fs_sim* sim);
 fs_status fs_slab_counters_read(fs_sim* sim, fs_slab_counters* out);   /* blocking */
 /* Live records (global cell keys) and their owned flags; blocking.  Returns n_live. */
 fs_status fs_slab_download(fs_sim* sim, fs_particle* dst, uint8_t* owned, size_t cap, uint32_t* n_live);

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(fs):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fluidsim.h but not exported"
     assert set(names) == set(fs._abi.PROTOTYPES), "ctypes prototypes out of sync with the header"
-    assert lib.fs_abi_version() == 1
+    assert lib.fs_abi_version() == 2
 
 
 def test_struct_sizes_match_header(fs):
@@ -120,7 +120,7 @@ def test_header_is_plain_c(fs, tmp_path):
                            "-lfluidsim_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert f"abi 1 symbols {len(names)}" in out.stdout
+    assert f"abi 2 symbols {len(names)}" in out.stdout
 
 
 def test_comm_failure_is_fs_err_comm(fs, tmp_path):

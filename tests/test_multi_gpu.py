@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class InProcessSlabs:
-    def __init__(self, fs, settings, off, world, cap, recv, seed=None, vel=1.0, sort_mode=None, trim_margin=0):
+    def __init__(self, fs, settings, off, world, cap, recv, seed=None, vel=1.0, sort_mode=None, trim_margin=0, serial=False,
+                 boundary_cols=None):
         from gpu_fluid_simulation_amd import multi
         self.fs, self.multi, self.world, self.trim_margin = fs, multi, world, trim_margin
         lat = fs.reference_lattice(settings, off)
@@ -32,7 +33,10 @@ class InProcessSlabs:
         self.sims, self.bufs = [], []
         for r in range(world):
             s = fs.SlabSimulation(settings, self.bounds[r], self.bounds[r + 1], r > 0, r < world - 1, cap, recv,
-                                  max_cols=self.gw, device=0, sort_mode=sort_mode)
+                                  max_cols=self.gw, device=0, sort_mode=sort_mode, serial=serial)
+            assert s.overlapped == (not serial and sort_mode in (None, fs.FS_SORT_COUNTING))
+            if boundary_cols is not None and s.overlapped:
+                s.set_boundary_cols(boundary_cols)
             s.upload_owned(lat[(cols >= self.bounds[r]) & (cols < self.bounds[r + 1])])
             self.sims.append(s)
             self.bufs.append({k: fs.ResizableBuffer(k, np.uint8, s.message_bytes) for k in ("sl", "sr")})
@@ -82,11 +86,13 @@ class InProcessSlabs:
             assert c["lost"] == 0 and c["overflow"] == 0 and c["far_halo"] == 0, c
 
 
-@pytest.mark.parametrize("world,n,seed", [(2, 4096, None), (3, 4096, 7), (4, 16384, 3), (8, 65536, 5)])
-def test_slabs_match_single_gpu(fs, world, n, seed):
+@pytest.mark.parametrize("world,n,seed,serial", [(2, 4096, None, False), (3, 4096, 7, False), (4, 16384, 3, False),
+                                                 (8, 65536, 5, False), (3, 4096, 7, True), (8, 65536, 5, True)])
+def test_slabs_match_single_gpu(fs, world, n, seed, serial):
+    """Default = the overlapped step (interior while the messages fly, boundary strips afterwards); serial = the round-3 step."""
     from tests.slab_oracle import assert_statistics_close, match_and_compare
     st, off, tick = fs.dam_break_2d(n)
-    slabs = InProcessSlabs(fs, st, off, world, cap=n + 4 * 2048, recv=2048, seed=seed)
+    slabs = InProcessSlabs(fs, st, off, world, cap=n + 4 * 2048, recv=2048, seed=seed, serial=serial)
     single = fs.FluidSimulation(st, device=0, initial_offset=off, ref_quirks=False)
     single.upload_particles(slabs.initial)
     assert slabs.owned().shape[0] == n
@@ -139,7 +145,7 @@ def test_slot_capacity_overflow_is_counted(fs):
     from gpu_fluid_simulation_amd import multi
     gh = int(np.ceil(np.float32(st.size.y) / np.float32(st.smoothing_radius))) + 2
     cap, rc = multi.slab_capacities(n, 2, gh)
-    roomy = InProcessSlabs(fs, st, off, 2, cap=cap, recv=rc)
+    roomy = InProcessSlabs(fs, st, off, 2, cap=cap, recv=rc, serial=True)
     owned_max = max(s.counters()["n_live"] for s in roomy.sims)       # before the first step: the uploaded owned particles
     for _ in range(12):
         roomy.step(tick)
@@ -147,7 +153,7 @@ def test_slot_capacity_overflow_is_counted(fs):
     assert roomy.owned().shape[0] == n
     recv = 2048
     main = owned_max + 64                                  # room for the owned share, none for the ~500 ghosts
-    tight = InProcessSlabs(fs, st, off, 2, cap=main + 2 * recv, recv=recv)
+    tight = InProcessSlabs(fs, st, off, 2, cap=main + 2 * recv, recv=recv, serial=True)
     tight.step(tick)
     live = [s.counters()["n_live"] for s in tight.sims]
     assert max(live) > main, (live, main)                  # the step left more live records than main slots
