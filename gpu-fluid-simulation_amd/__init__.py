@@ -22,6 +22,7 @@ from ._abi import (  # noqa: F401
     FS_SORT_BITONIC,
     FS_SORT_COUNTING,
     FS_SLAB_SERIAL,
+    FS_SLAB_STRIPS,
     PARTICLE3_DTYPE,
     PARTICLE_DTYPE,
     PASS_NAMES,
@@ -367,20 +368,22 @@ class SlabSimulation:
     """
 
     def __init__(self, settings, own_lo, own_hi, has_left, has_right, capacity, recv_capacity, max_cols, device=0,
-                 sort_mode=None, serial=False):
+                 sort_mode=None, serial=False, strips=False):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.settings = settings
-        mode = (0 if sort_mode is None else 1 + int(sort_mode)) | (FS_SLAB_SERIAL if serial else 0)
+        mode = (0 if sort_mode is None else 1 + int(sort_mode)) | (FS_SLAB_SERIAL if serial else 0) | (FS_SLAB_STRIPS if strips else 0)
         self.cfg = SlabConfig(int(own_lo), int(own_hi), int(bool(has_left)), int(bool(has_right)), int(capacity),
                               int(recv_capacity), int(max_cols), mode)
         _check(self._lib, self._lib.fs_slab_create(C.byref(settings), int(device), C.byref(self.cfg), C.byref(self._h)))
         self.capacity = int(capacity)
         self.device_index = int(device)
         self.message_bytes = int(self._lib.fs_slab_message_bytes(self._h))
-        # overlapped step (include/fluidsim.h fs_slab_pack): pack() also enqueues the interior columns' whole step,
-        # step() the boundary strips; the exchange in between runs on comm_stream_ptr
-        self.overlapped = bool(self._lib.fs_slab_overlapped(self._h))
+        # 0 serial step; 1 edge-first (default): step() advances the edge columns, builds the NEXT step's messages and only
+        # then advances the interior — the exchange runs beside that on comm_stream_ptr; 2 strips: pack() also enqueues the
+        # interior columns' whole step, step() the boundary strips (include/fluidsim.h)
+        self.step_mode = int(self._lib.fs_slab_overlapped(self._h))
+        self.overlapped = self.step_mode != 0
 
     def set_boundary_cols(self, cols):
         _check(self._lib, self._lib.fs_slab_set_boundary_cols(self._h, int(cols)))

@@ -167,6 +167,7 @@ FS_MATH_TOLERANCE = 2
 
 PASS_NAMES = ("predict_key", "sort", "reorder", "density", "force", "boundary")
 FS_SLAB_SERIAL = 0x100
+FS_SLAB_STRIPS = 0x200
 FS_EXPORT_PARTICLES = 0
 FS_EXPORT_START_INDICES = 1
 

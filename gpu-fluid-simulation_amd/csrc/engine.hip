@@ -154,10 +154,19 @@ struct fs_sim {
     // Overlapped slab step (counting sort only): fs_slab_pack enqueues the pack AND the whole step of the
     // interior columns; the halo exchange runs beside it on `comm`; fs_slab_step finishes the columns within `boundary_cols`
     // of a slab edge on the strip arrays (kernels_slab.hip "boundary strips").
-    bool overlap = false;
+    bool transposed = false;               // cell ids column-major (fs_device.h StepParams::transposed): ranks with neighbours, not the strip step
+    bool overlap = false;                  // FS_SLAB_STRIPS: ghosts stay out of the main array, boundary strips after the exchange
+    bool edge_first = false;               // the default: the next step's messages are built right after the edge columns' force launch
+    bool prepacked = false;                // edge-first: the send buffers hold the messages of tick + 1 ...
+    void *pp_left = nullptr, *pp_right = nullptr;   // ... these buffers (the ones the last fs_slab_pack was given)
+    float pp_delta = 0.0f;                 // ... built with this delta
+    uint32_t pp_lo = 0, pp_hi = 0;         // ... and this owned window
+    uint32_t msg_epoch = 0;                // one number per k_slab_msg launch (its look-back state is never cleared)
+    fs_tick_settings last_tick{};
     hipStream_t comm = nullptr;            // the exchange's stream (fs_slab_exchange, or the caller's transport between comm_begin / comm_end)
     hipEvent_t ev_packed = nullptr;        // main stream: both outgoing messages are complete
     hipEvent_t ev_exch = nullptr;          // comm stream: both incoming messages have arrived
+    hipEvent_t ev_fork2 = nullptr;         // edge-first: the density pass is done, the edge columns' chain may start on `comm`
     bool exch_pending = false;             // fs_slab_step must wait for ev_exch
     uint32_t boundary_cols = 4;            // owned columns per neighboured edge left to the strips (>= 3)
     uint32_t pending_shift = 0;            // columns a window edge moved since the last pack: that step's migrants land deeper
@@ -197,8 +206,9 @@ struct fs_sim {
         hist.release(); strip.release();
         if (ev_packed) (void)hipEventDestroy(ev_packed);
         if (ev_exch) (void)hipEventDestroy(ev_exch);
+        if (ev_fork2) (void)hipEventDestroy(ev_fork2);
         if (comm) (void)hipStreamDestroy(comm);
-        comm = nullptr; ev_packed = ev_exch = nullptr;
+        comm = nullptr; ev_packed = ev_exch = ev_fork2 = nullptr;
         for (auto& e : ev) (void)hipEventDestroy(e);
         ev.clear();
         sortp.release();
@@ -324,7 +334,10 @@ fsd::StepParams make_params(const fs_sim& s) {
         P.ref_quirks = 0;   // the global stale-start quirk cannot exist per rank (§8e)
         // the serial step advances every owned column in its one force launch; the overlapped step narrows this per launch
         P.adv_lo = P.own_lo; P.adv_hi = P.own_hi; P.adv_outside = 0;
+        P.transposed = s.transposed ? 1 : 0;
     }
+    P.grid_u = P.transposed ? P.grid_h : P.grid_w;
+    P.grid_v = P.transposed ? P.grid_w : P.grid_h;
     return P;
 }
 
@@ -467,6 +480,9 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
+
+// workgroups of the edge columns' launches in an edge-first step with column-major ids (each walks the device-side block ranges)
+#define FS_EDGE_GRID 1024u
 
 // ---- overlapped slab step --------------------------------------------------------------------------
 // Step parameters of the two force launches of an overlapped step: the interior launch (main array) and the strip launch.
@@ -1089,8 +1105,19 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     // default to the O(N) counting sort; cfg->sort_mode = 1 + FS_SORT_BITONIC selects the network
     s->opts.sort_mode = (cfg->sort_mode & 0xFFu) == 1 + FS_SORT_BITONIC ? FS_SORT_BITONIC : FS_SORT_COUNTING;
     {   // the overlapped step needs the counting sort (ghosts out of the main array); FS_SLAB_SERIAL / FS_SLAB_OVERLAP=0: the serial step
-        const char* e = getenv("FS_SLAB_OVERLAP");
-        s->overlap = s->opts.sort_mode == FS_SORT_COUNTING && !(cfg->sort_mode & FS_SLAB_SERIAL) && !(e && atoi(e) == 0);
+        // FS_SLAB_MODE=serial|edge|strips overrides the configuration (A/B runs)
+        const char* e = getenv("FS_SLAB_MODE");
+        uint32_t m = (cfg->sort_mode & FS_SLAB_SERIAL) ? 0u : (cfg->sort_mode & FS_SLAB_STRIPS) ? 2u : 1u;
+        if (e) m = !strcmp(e, "serial") ? 0u : !strcmp(e, "strips") ? 2u : !strcmp(e, "edge") ? 1u : m;
+        if (s->opts.sort_mode != FS_SORT_COUNTING) m = 0u;     // the network's slab mode stays the serial step (bit-identity with the plain engine)
+        s->overlap = m == 2u;
+        s->edge_first = m == 1u;
+        // column-major cell ids wherever a slab edge has a neighbour (the edge columns are then whole blocks at the two ends of the
+        // sorted array); a slab without neighbours keeps the reference layout and stays bit-identical to the plain engine in
+        // FS_SORT_COUNTING mode.  FS_SLAB_TRANSPOSE=0/1 overrides (A/B runs); the strip step's gather is written for rows.
+        const char* te = getenv("FS_SLAB_TRANSPOSE");
+        s->transposed = s->opts.sort_mode == FS_SORT_COUNTING && !s->overlap && (cfg->has_left || cfg->has_right) && !(cfg->sort_mode & FS_SLAB_ROWMAJOR);
+        if (te && s->opts.sort_mode == FS_SORT_COUNTING && !s->overlap) s->transposed = atoi(te) != 0;
     }
     s->device = device;
     s->slab = true;
@@ -1128,11 +1155,11 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->owned.alloc(cap));
     const size_t nblocks = (cap + 255) / 256;
-    FS_TRY(s->blockcnt.alloc(nblocks + 1));
+    FS_TRY(s->blockcnt.alloc(2 * (nblocks + 1)));      // per 256-slot block: message counts, then message offsets (k_slab_msg)
     FS_TRY(s->stage.alloc(fsd::slab_stage_words((uint32_t)cap)));
     FS_TRY(s->msg_state.alloc(fsd::slab_msg_groups((uint32_t)cap) + 1));
     FS_TRY(hipMemsetAsync(s->msg_state.p, 0, s->msg_state.n * sizeof(fsd::u64), s->stream));
-    FS_TRY(s->slab_counters.alloc(8));
+    FS_TRY(s->slab_counters.alloc(16));
     FS_TRY(s->hist.alloc(gw));
     FS_TRY(s->csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
     FS_TRY(hipMemsetAsync(s->csort.p, 0, s->csort.n * sizeof(uint32_t), s->stream));       // histogram / tickets: zero between steps
@@ -1142,11 +1169,16 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(s->counter.alloc(8));
     FS_TRY(s->aos.alloc(cap));
     FS_TRY(hipEventCreate(&s->t0)); FS_TRY(hipEventCreate(&s->t1));
-    if (s->overlap) {
-        FS_TRY(hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking));
+    if (s->overlap || s->edge_first) {
+        int lo_prio = 0, hi_prio = 0;          // the exchange's kernel should not queue behind the interior columns' workgroups
+        (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+        FS_TRY(hipStreamCreateWithPriority(&s->comm, hipStreamNonBlocking, hi_prio));
         FS_TRY(hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming));
         FS_TRY(hipEventCreateWithFlags(&s->ev_exch, hipEventDisableTiming));
+        FS_TRY(hipEventCreateWithFlags(&s->ev_fork2, hipEventDisableTiming));
         if (const char* e = getenv("FS_SLAB_BOUNDARY_COLS")) s->boundary_cols = (uint32_t)atoi(e) < 3u ? 3u : (uint32_t)atoi(e);
+    }
+    if (s->overlap) {
         // The strip could hold every particle of a narrow slab (all columns within the boundary zone) plus both messages:
         // same capacity as the main array (memory is not the constraint: ~100 B per slot); its kernels cover the slots in use only.
         fs_sim::Strip& T = s->strip;
@@ -1169,7 +1201,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(hipMemsetAsync(s->cs.p, 0, s->cs.n * sizeof(uint32_t), s->stream));
     if (s->tex.n) FS_TRY(hipMemsetAsync(s->tex.p, 0, s->tex.n * sizeof(float2), s->stream));
     FS_TRY(hipMemsetAsync(s->counter.p, 0, 8 * sizeof(uint32_t), s->stream));
-    FS_TRY(hipMemsetAsync(s->slab_counters.p, 0, 8 * sizeof(uint32_t), s->stream));
+    FS_TRY(hipMemsetAsync(s->slab_counters.p, 0, 16 * sizeof(uint32_t), s->stream));
     FS_TRY(hipMemsetAsync(s->owned.p, 0, cap, s->stream));
     FS_TRY(hipMemsetAsync(s->rho.p, 0, cap * sizeof(float), s->stream));
     FS_TRY(hipMemsetAsync(s->pos.p, 0, cap * sizeof(float2), s->stream));
@@ -1227,8 +1259,8 @@ fs_status fs_slab_set_boundary_cols(fs_sim* s, uint32_t cols) {
     s->boundary_cols = cols < 3u ? 3u : cols;
     return FS_OK;
 }
-uint32_t fs_slab_boundary_cols(const fs_sim* s) { return (s && s->slab && s->overlap) ? s->boundary_cols : 0u; }
-int fs_slab_overlapped(const fs_sim* s) { return (s && s->slab && s->overlap) ? 1 : 0; }
+uint32_t fs_slab_boundary_cols(const fs_sim* s) { return (s && s->slab && (s->overlap || s->edge_first)) ? s->boundary_cols : 0u; }
+int fs_slab_overlapped(const fs_sim* s) { return (s && s->slab) ? (s->edge_first ? 1 : s->overlap ? 2 : 0) : 0; }
 void* fs_slab_comm_stream(const fs_sim* s) { return (s && s->slab) ? (void*)s->comm : nullptr; }
 
 /* Transport hooks of the overlapped step (a no-op on a serial handle, whose exchange is ordered by the simulation's stream):
@@ -1237,7 +1269,7 @@ void* fs_slab_comm_stream(const fs_sim* s) { return (s && s->slab) ? (void*)s->c
  * three itself.  fs_slab_wait_packed blocks the HOST until the outgoing messages are complete (host-staged transports). */
 fs_status fs_slab_comm_begin(fs_sim* s) {
     if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
-    if (!s->overlap) return FS_OK;
+    if (!s->comm) return FS_OK;
     FS_HIP(hipSetDevice(s->device));
     if (!s->slab_packed) FS_HIP(hipEventRecord(s->ev_packed, s->stream));   // outside a step: behind whatever the simulation's stream holds
     FS_HIP(hipStreamWaitEvent(s->comm, s->ev_packed, 0));
@@ -1245,7 +1277,7 @@ fs_status fs_slab_comm_begin(fs_sim* s) {
 }
 fs_status fs_slab_comm_end(fs_sim* s) {
     if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
-    if (!s->overlap) return FS_OK;
+    if (!s->comm) return FS_OK;
     FS_HIP(hipSetDevice(s->device));
     FS_HIP(hipEventRecord(s->ev_exch, s->comm));
     s->exch_pending = true;
@@ -1254,7 +1286,7 @@ fs_status fs_slab_comm_end(fs_sim* s) {
 fs_status fs_slab_wait_packed(fs_sim* s) {
     if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
     FS_HIP(hipSetDevice(s->device));
-    if (s->overlap && s->slab_packed) FS_HIP(hipEventSynchronize(s->ev_packed));
+    if (s->comm && s->slab_packed) FS_HIP(hipEventSynchronize(s->ev_packed));
     else FS_HIP(hipStreamSynchronize(s->stream));
     return FS_OK;
 }
@@ -1280,17 +1312,27 @@ fs_status fs_slab_pack(fs_sim* s, const fs_tick_settings* t, void* send_left, vo
         FS_HIP(hipEventRecord(s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)], s->stream));
     }
     const bool counting = s->opts.sort_mode == FS_SORT_COUNTING;
+    // edge-first step: are the messages of this tick already in the send buffers (built by the last fs_slab_step)?  Only if
+    // nothing they depend on has changed since: buffers, owned window, delta.
+    const bool pre = s->edge_first && s->prepacked && s->pp_left == (s->slab_cfg.has_left ? send_left : nullptr) &&
+                     s->pp_right == (s->slab_cfg.has_right ? send_right : nullptr) && s->pp_delta == t->delta &&
+                     s->pp_lo == s->slab_cfg.own_lo && s->pp_hi == s->slab_cfg.own_hi;
+    s->prepacked = false;
+    s->pp_left = s->slab_cfg.has_left ? send_left : nullptr;
+    s->pp_right = s->slab_cfg.has_right ? send_right : nullptr;
+    s->last_tick = *t;
     fsd::launch_slab_pack(s->stream, P, s->slab_main, s->slab_cfg.recv_capacity, (int)s->slab_cfg.has_left,
                           (int)s->slab_cfg.has_right, s->pos.p, s->vel.p, s->owned.p,
                           counting ? fsd::counting_sort_kt(s->csort.p, s->capacity, s->ncell) : s->pairs.p,
-                          fsd::counting_sort_hist(s->csort.p), s->blockcnt.p, s->stage.p, s->msg_state.p, s->tick,
-                          s->slab_cfg.has_left ? send_left : nullptr,
-                          s->slab_cfg.has_right ? send_right : nullptr, s->slab_counters.p, s->counter.p, s->safe.p, counting,
-                          s->overlap);
+                          fsd::counting_sort_hist(s->csort.p), s->blockcnt.p, s->stage.p, s->msg_state.p, ++s->msg_epoch,
+                          s->pp_left, s->pp_right, s->slab_counters.p, s->counter.p, s->safe.p, counting,
+                          s->overlap, !pre, s->key.p, s->adv_lo, s->adv_hi);
     FS_HIP(hipGetLastError());
     s->slab_packed = true;
     s->state_lo = s->slab_cfg.own_lo; s->state_hi = s->slab_cfg.own_hi;
     if (s->overlap) return slab_interior(s);
+    // edge-first: a pre-built message set was recorded complete (ev_packed) when it was built; a fresh one is complete now
+    if (s->edge_first && !pre) FS_HIP(hipEventRecord(s->ev_packed, s->stream));
     return FS_OK;
 }
 
@@ -1305,6 +1347,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     hipStream_t st = s->stream;
     hipEvent_t* ev = s->slab_prof ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
     const bool counting = s->opts.sort_mode == FS_SORT_COUNTING;
+    if (s->exch_pending) { FS_HIP(hipStreamWaitEvent(st, s->ev_exch, 0)); s->exch_pending = false; }
     fsd::launch_slab_unpack(st, P, s->slab_main, s->slab_cfg.recv_capacity, s->slab_cfg.has_left ? recv_left : nullptr,
                             s->slab_cfg.has_right ? recv_right : nullptr, s->pos.p, s->vel.p,
                             counting ? fsd::counting_sort_kt(s->csort.p, s->capacity, s->ncell) : s->pairs.p,
@@ -1318,21 +1361,84 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
         fsd::launch_bitonic_sort(st, s->pairs.p, s->capacity, s->sort_dirty.p, nullptr, nullptr, nullptr, nullptr, &per_stage);
     }
     if (ev) FS_HIP(hipEventRecord(ev[2], st));
+    const bool edge_step = s->edge_first && (s->slab_cfg.has_left || s->slab_cfg.has_right);
+    bool forked = false;
+    if (edge_step) {
+        plan_overlap(s);
+        forked = s->transposed && s->adv_lo < s->adv_hi;      // the edge columns' chain forks off behind the reorder pass (below)
+    }
     if (counting)
         fsd::launch_counting_reorder_slab(st, P, s->capacity, s->ncell, s->csort.p, s->pairs.p, s->cs.p, s->pos.p, s->vel.p, s->pos_s.p,
                                           s->vel_s.p, s->pred.p, s->key.p, s->owned.p, s->start_ref.p, s->safe.p, s->fdefer.p,
-                                          s->counter.p + 4);
+                                          s->counter.p + 4, nullptr, forked ? s->ev_fork2 : nullptr);
     else
         fsd::launch_slab_reorder(st, P, s->capacity, s->pairs.p, s->pos.p, s->vel.p, s->pos_s.p, s->vel_s.p, s->pred.p,
                                  s->key.p, s->owned.p, s->cs.p, s->start_ref.p, s->work.p, s->counter.p, s->work_cap,
                                  s->slab_counters.p, s->safe.p, s->fdefer.p, s->counter.p + 4);
     if (ev) FS_HIP(hipEventRecord(ev[3], st));
+    if (edge_step) {
+        if (forked) {
+            // column-major ids: the edge columns' chain forks off BEFORE the density pass — their own density launch (the few
+            // hundred blocks that hold the edge columns and one column more on either side; the full launch below computes the
+            // same values again) runs on the exchange stream, so the chain is done, and the exchange under way, early in the
+            // interior columns' force pass
+            fsd::StepParams PD = P;
+            PD.adv_lo = s->adv_lo; PD.adv_hi = s->adv_hi;
+            FS_HIP(hipStreamWaitEvent(s->comm, s->ev_fork2, 0));     // signalled by the reorder kernel itself
+            fsd::launch_density(s->comm, PD, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p, s->fdefer.p,
+                                s->fwork.p, s->counter.p + 4, FS_EDGE_GRID);
+        }
+    }
     fsd::launch_density(st, P, s->pred.p, s->cs.p, s->start_ref.p, s->pairs.p, s->safe.p, s->rho.p, s->rho2.p, s->fdefer.p, s->fwork.p, s->counter.p + 4);
     if (ev) FS_HIP(hipEventRecord(ev[4], st));
-    fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                      s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
-                      s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint());
-    if (ev) { FS_HIP(hipEventRecord(ev[5], st)); FS_HIP(hipEventRecord(ev[6], st)); s->prof_pending += 1; }
+    if (edge_step) {
+        // Edge-first step.  Behind the density pass the stream forks: the handle's exchange stream (high priority) advances
+        // the owned columns within boundary_cols of a neighboured edge — a few hundred blocks, latency-bound — then builds the
+        // NEXT step's messages from their new state (k_slab_prepack .. k_slab_gather) and carries the exchange of those
+        // messages (fs_slab_exchange / the caller's transport between fs_slab_comm_begin / _end); the simulation's stream
+        // runs the force pass of the interior columns beside all that, and joins before anything reads the new state.
+        fsd::StepParams PE = P, PI = P;
+        PE.adv_lo = PI.adv_lo = s->adv_lo; PE.adv_hi = PI.adv_hi = s->adv_hi;
+        PE.adv_outside = 1; PI.adv_outside = 0;
+        // column-major ids: the edge columns are a few hundred consecutive blocks at the two ends of the sorted array, walked by
+        // small fixed grids (fs_device.h EdgeBlocks)
+        const uint32_t eg = s->transposed ? FS_EDGE_GRID : 0u;
+        hipStream_t es = s->comm;
+        if (!forked) {
+            FS_HIP(hipEventRecord(s->ev_fork2, st));
+            FS_HIP(hipStreamWaitEvent(es, s->ev_fork2, 0));
+        }
+        fsd::launch_force(es, PE, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
+                          s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, nullptr,
+                          nullptr, nullptr, 256u, nullptr, eg);
+        {   // what fs_slab_pack will see at tick + 1, if nothing changes in between (it checks)
+            fs_uniform un;
+            host_uniform(s->settings, s->last_tick, s->tick + 1, &un);
+            const fs_uniform keep = s->uniform;
+            s->uniform = un;
+            fsd::StepParams PN = make_params(*s);
+            s->uniform = keep;
+            PN.adv_lo = s->adv_lo; PN.adv_hi = s->adv_hi; PN.adv_outside = 1;
+            fsd::launch_slab_prepack(es, PN, s->capacity, s->slab_cfg.recv_capacity, (int)s->slab_cfg.has_left, (int)s->slab_cfg.has_right,
+                                     s->pos.p, s->vel.p, s->owned.p, s->key.p, s->blockcnt.p, s->stage.p, s->msg_state.p, ++s->msg_epoch,
+                                     s->pp_left, s->pp_right, s->slab_counters.p, s->cs.p, eg);
+            FS_HIP(hipEventRecord(s->ev_packed, es));       // the next step's messages are complete (and the edge columns advanced)
+            s->prepacked = true;
+            s->pp_delta = s->last_tick.delta; s->pp_lo = s->slab_cfg.own_lo; s->pp_hi = s->slab_cfg.own_hi;
+        }
+        if (s->adv_lo < s->adv_hi)
+            fsd::launch_force(st, PI, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
+                              s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
+                              s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint());
+        if (ev) FS_HIP(hipEventRecord(ev[5], st));      // FS_PASS_FORCE: the interior launch
+        FS_HIP(hipStreamWaitEvent(st, s->ev_packed, 0));  // join: the next pack (and any download) sees the edge columns' new state
+        if (ev) { FS_HIP(hipEventRecord(ev[6], st)); s->prof_pending += 1; }     // FS_PASS_BOUNDARY: what the join still had to wait for
+    } else {
+        fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
+                          s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
+                          s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint());
+        if (ev) { FS_HIP(hipEventRecord(ev[5], st)); FS_HIP(hipEventRecord(ev[6], st)); s->prof_pending += 1; }
+    }
     FS_HIP(hipGetLastError());
     s->slab_packed = false;
     return FS_OK;

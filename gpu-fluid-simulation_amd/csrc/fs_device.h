@@ -56,6 +56,13 @@ struct StepParams {
     // (the boundary strips, computed after the unpack).  Global columns, own_lo <= adv_lo <= adv_hi <= own_hi.
     uint32_t adv_lo, adv_hi;
     int32_t adv_outside;
+    // --- cell-id layout.  Ids are v * grid_u + u: `u` runs along the axis whose three neighbour cells are consecutive ids (one
+    // contiguous index range per sweep "row"), `v` along the other.  Reference layout (funcs.wgsl:216-218): u = x, v = y.
+    // transposed (slab ranks with neighbours): u = y, v = x (local column) — a rank's cell COLUMNS become contiguous index
+    // ranges, so the columns next to a slab edge (the halo, the edge-first force launch, the next step's messages) are a few
+    // hundred whole blocks at the two ends of the sorted array instead of a few lanes of every grid row.
+    uint32_t grid_u, grid_v;
+    int32_t transposed;
 };
 
 // Slab mode: does the force pass of this launch advance a particle whose GLOBAL cell column is cg?  (Ghosts — columns outside
@@ -115,6 +122,24 @@ __device__ __forceinline__ uint32_t cell_of_point(const StepParams& P, float2 pt
 __device__ __forceinline__ void xy_local(const StepParams& P, float2 pt, uint32_t* cx, uint32_t* cy) {
     xy_of_point(P, pt, cx, cy);
     *cx = (uint32_t)((int32_t)*cx - P.col_origin);
+}
+// The same as (u, v) of the handle's cell-id layout (StepParams::transposed), plus the GLOBAL cell column.
+__device__ __forceinline__ void uv_local(const StepParams& P, float2 pt, uint32_t* u, uint32_t* v, int32_t* col_global) {
+    uint32_t cx, cy;
+    xy_of_point(P, pt, &cx, &cy);
+    *col_global = (int32_t)cx;
+    cx = (uint32_t)((int32_t)cx - P.col_origin);
+    *u = P.transposed ? cy : cx;
+    *v = P.transposed ? cx : cy;
+}
+__device__ __forceinline__ uint32_t key_of_local(const StepParams& P, uint32_t cx_local, uint32_t cy) {
+    return P.transposed ? cx_local * P.grid_u + cy : cy * P.grid_u + cx_local;
+}
+// (local column, row) of a cell id
+__device__ __forceinline__ void key_to_local(const StepParams& P, uint32_t key, uint32_t* cx_local, uint32_t* cy) {
+    const uint32_t v = key / P.grid_u, u = key - v * P.grid_u;
+    *cx_local = P.transposed ? v : u;
+    *cy = P.transposed ? u : v;
 }
 
 // funcs.wgsl:129-149
@@ -230,6 +255,36 @@ __device__ __forceinline__ bool xcd_block(const StepParams& P, uint32_t nblocks,
     *logical = lb;
     return lb < nblocks;
 }
+
+// ---- edge-first slab step, column-major ids: the blocks that hold the edge columns ------------------------------------
+// With StepParams::transposed a rank's cell columns are contiguous index ranges of the sorted array, so the columns left of the
+// interior [adv_lo, adv_hi) are the blocks [0, eL) and the ones right of it the blocks [eR, nb).  The edge columns' kernels are
+// launched with a SMALL fixed grid that walks exactly these blocks (the counts live in the device-side cell table): a launch
+// over all of a rank's ~8 000 blocks, most of which return at once, still has to find a wave slot for each of them — beside
+// the interior columns' kernels, which keep every slot busy, that alone took ~20 us per launch.
+// `extra`: columns of the interior to include as well (the density launch needs one).
+struct EdgeBlocks { uint32_t eL, eR, nb; };
+__device__ __forceinline__ EdgeBlocks edge_blocks(const StepParams& P, const uint32_t* __restrict__ cs, uint32_t n, uint32_t extra) {
+    EdgeBlocks E;
+    E.nb = (n + 255u) / 256u;
+    E.eL = 0u; E.eR = E.nb;
+    if (P.adv_lo > P.own_lo) {
+        uint32_t c = (uint32_t)((int32_t)P.adv_lo - P.col_origin) + extra;       // first local column not needed
+        if (c > P.grid_v) c = P.grid_v;
+        const uint32_t e = (cs[c * P.grid_u] + 255u) / 256u;
+        E.eL = e < E.nb ? e : E.nb;
+    }
+    if (P.adv_hi < P.own_hi) {
+        const uint32_t c = (uint32_t)((int32_t)P.adv_hi - P.col_origin) - extra;  // first local column needed
+        const uint32_t b = cs[c * P.grid_u] / 256u;
+        E.eR = b < E.nb ? b : E.nb;
+    }
+    if (E.eR < E.eL) E.eR = E.eL;                    // the two ends meet: every block once
+    return E;
+}
+__device__ __forceinline__ uint32_t edge_block_count(const EdgeBlocks& E) { return E.eL + (E.nb - E.eR); }
+__device__ __forceinline__ uint32_t edge_block_at(const EdgeBlocks& E, uint32_t t) { return t < E.eL ? t : E.eR + (t - E.eL); }
+__device__ __forceinline__ bool edge_block_has(const EdgeBlocks& E, uint32_t b) { return b < E.eL || (b >= E.eR && b < E.nb); }
 
 // ---- block neighbour tiles (shared by the 2D and 3D density / force kernels) ------------------
 // A 256-thread workgroup owns 256 consecutive sorted particles (a strip of cells in one grid

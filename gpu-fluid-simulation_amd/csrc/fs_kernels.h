@@ -18,7 +18,8 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
                     const uint32_t* start_ref, const u64* pairs, const unsigned long long* safe, float* rho,
                     float2* rho2 /* {rho, +-RN(1/rho)}: the sign is the particle's safe-operand classification */,
-                    uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count /* force pass: pre-registered waves */);
+                    uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count /* force pass: pre-registered waves */,
+                    uint32_t edge_grid = 0 /* != 0: edge-first slab step, column-major ids: only the blocks of the edge columns (+1), walked by this many workgroups */);
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out, const float* rho_arr, uint32_t* defer_bits /* per block */,
@@ -27,7 +28,8 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
                   hipStream_t side = nullptr /* second stream: the pre-registered general work runs beside the lean kernel */,
                   hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr,
                   uint32_t general_grid = 0 /* workgroups of the general kernel; 0: the full grid */,
-                  uint32_t* general_hint = nullptr /* host-visible word: entries the general kernel found in its lists */);
+                  uint32_t* general_hint = nullptr /* host-visible word: entries the general kernel found in its lists */,
+                  uint32_t edge_grid = 0 /* != 0: the lean kernel walks only the blocks of the edge columns with this many workgroups */);
 // pairs != nullptr: the keys are the high words of the sorted pairs (the state of the last step; launch_reorder with
 // key_s == nullptr does not store them a second time), else `key` (an uploaded state).
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,
@@ -59,7 +61,17 @@ void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, 
                       int has_right, const float2* pos, const float2* vel, const unsigned char* owned, u64* out,
                       uint32_t* hist, void* blockcnt, uint32_t* stage, void* state, uint32_t epoch,
                       void* msg_left, void* msg_right, uint32_t* counters, uint32_t* gap_counter, unsigned long long* safe,
-                      bool counting, bool overlap = false /* the slots past main_slots hold last step's migrants (overlapped step) */);
+                      bool counting, bool overlap = false /* the slots past main_slots hold last step's migrants (strip step) */,
+                      bool lists = true /* false: the messages were pre-built (launch_slab_prepack): only check that every particle
+                                           the full classification flags was in the edge zone [own_lo, prev_adv_lo) u [prev_adv_hi, own_hi)
+                                           of the last step (key_prev: its sorted keys) */,
+                      const uint32_t* key_prev = nullptr, uint32_t prev_adv_lo = 0, uint32_t prev_adv_hi = 0);
+// Edge-first step: the NEXT step's messages from the particles the StepParams::adv_outside force launch has just advanced.
+// `P_next`: window + tick constants of the next pack, adv_* as in that force launch; `epoch` unique among the handle's k_slab_msg launches.
+void launch_slab_prepack(hipStream_t st, const StepParams& P_next, uint32_t cap, uint32_t R, int has_left, int has_right,
+                         const float2* pos, const float2* vel, const unsigned char* owned, const uint32_t* key_s, void* blockcnt,
+                         uint32_t* stage, void* state, uint32_t epoch, void* msg_left, void* msg_right, uint32_t* counters,
+                         const uint32_t* cs, uint32_t edge_grid = 0 /* != 0 (column-major ids): walk only the edge columns' blocks */);
 // Overlapped slab step — the boundary strips (kernels_slab.hip).  `P` = the main array's StepParams; win[4] = the two strip
 // windows as LOCAL column ranges [win[0], win[1]) and [win[2], win[3]); strip_counters: [0] live strip particles (written by the
 // strip's scan), [1] slots filled from the main array, [2] slots in use.
@@ -142,6 +154,6 @@ void launch_counting_reorder_slab(hipStream_t st, const StepParams& P, uint32_t 
                                   const uint32_t* cs, const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s,
                                   float2* pred_s, uint32_t* key_s, unsigned char* owned, uint32_t* start_ref,
                                   unsigned long long* safe, uint32_t* force_defer, uint32_t* force_work_count,
-                                  const uint32_t* n_dev = nullptr);
+                                  const uint32_t* n_dev = nullptr, hipEvent_t done = nullptr /* signalled by the kernel's completion */);
 
 }  // namespace fsd

@@ -5,6 +5,8 @@
 // Deterministic (no dependence on atomic arrival order):
 // (atomics only hand out tickets; the final order inside a cell is by source index) — kernels below.
 // The pairs then feed the same density / force chain as the bitonic mode.
+#include <hip/hip_ext.h>
+
 #include "fs_device.h"
 #include "fs_kernels.h"
 #include "fs_scan.h"
@@ -191,8 +193,9 @@ __global__ __launch_bounds__(CS_BLOCK) void k_cs_fixreorder(StepParams P, uint32
     if (key_s) key_s[d] = key;
     if (!kin_safe(pd, v)) atomicAnd(&safe[d >> 6], ~(1ull << (d & 63u)));   // rare; words preset to all-ones
     if (SLAB) {
-        const uint32_t cy = key / P.grid_w;
-        const int32_t cxg = (int32_t)(key - cy * P.grid_w) + P.col_origin;
+        uint32_t cxl, cy;
+        key_to_local(P, key, &cxl, &cy);
+        const int32_t cxg = (int32_t)cxl + P.col_origin;
         owned[d] = (cxg >= (int32_t)P.own_lo && cxg < (int32_t)P.own_hi) ? 1 : 0;
     }
     if (rank == 0u && key < P.ncell) {           // first particle of its cell: compute.wgsl:49-55 (index 0 skipped)
@@ -236,8 +239,15 @@ void launch_counting_reorder_slab(hipStream_t st, const StepParams& P, uint32_t 
                                   const uint32_t* cs, const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s,
                                   float2* pred_s, uint32_t* key_s, unsigned char* owned, uint32_t* start_ref,
                                   unsigned long long* safe, uint32_t* force_defer, uint32_t* force_work_count,
-                                  const uint32_t* n_dev) {
+                                  const uint32_t* n_dev, hipEvent_t done) {
     const CsLayout L = cs_layout(scratch, cap, ncell_alloc);
+    if (done) {   // the kernel's own completion signal is the event: no separate barrier packet in the stream (hipEventRecord costs
+                  // the following kernel ~6 us of idle queue)
+        hipExtLaunchKernelGGL(k_cs_fixreorder<true>, dim3((cap + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, nullptr, done, 0, P, cap,
+                              L.kt, cs, L.slot_src, pairs, pos_in, vel_in, pos_s, vel_s, pred_s, key_s, owned, start_ref, safe, force_defer,
+                              force_work_count, n_dev);
+        return;
+    }
     hipLaunchKernelGGL(k_cs_fixreorder<true>, dim3((cap + CS_BLOCK - 1) / CS_BLOCK), dim3(CS_BLOCK), 0, st, P, cap, L.kt, cs,
                        L.slot_src, pairs, pos_in, vel_in, pos_s, vel_s, pred_s, key_s, owned, start_ref, safe, force_defer, force_work_count,
                        n_dev);

@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t slab_key(const StepParams& P, float2 pred, u
     *cx_global = cx;
     const int32_t lo = (int32_t)P.own_lo - 2, hi = (int32_t)P.own_hi + 2;   // owned + 2 ghost columns per side
     if ((int32_t)cx < lo || (int32_t)cx >= hi || cy >= P.grid_h) return FS_DEAD_KEY;
-    return cy * P.grid_w + (uint32_t)((int32_t)cx - P.col_origin);
+    return key_of_local(P, (uint32_t)((int32_t)cx - P.col_origin), cy);
 }
 
 struct SlabHeader { uint32_t count, overflow, pad0, pad1; };
@@ -43,24 +43,49 @@ struct SlabHeader { uint32_t count, overflow, pad0, pad1; };
 //                 needs no pass of its own over the slots; bitonic mode: pairs[i] = key << 32 | i as before;
 //               * the slots each neighbour needs (migrants + the 2-column halo) are listed per 256-slot block, in slot
 //                 order (stage_l / stage_r, 256 entries per block), with the two counts in blockcnt[block];
-//  k_slab_msg   one workgroup per MSG_GROUP blocks: exclusive offsets of its blocks by a wave scan + a decoupled
-//               look-back over the (few) workgroups (fs_scan.h), then the listed records are gathered into the two
-//               fixed-size messages in SLOT ORDER (deterministic); the last workgroup writes the two headers.
+//  k_slab_msg   one wave per MSG_GROUP blocks: exclusive message offsets of its blocks by a wave scan + a decoupled
+//               look-back over the (few) groups (fs_scan.h); the last group writes the two headers;
+//  k_slab_gather one workgroup per block: its listed records -> the two fixed-size messages, in SLOT ORDER (deterministic).
 // (A look-back over the 256-slot blocks themselves — one launch — was measured first: its prefix frontier advances ~128
 //  blocks per global-memory round trip, 0.17 ms for the 11 136 blocks of an 8-way rank.  The chain must be short.)
+// The slots of one 256-slot block each message needs (flag bit 0: left, bit 1: right), listed in slot order (stage_l / stage_r,
+// 256 entries per block) with the two counts in blockcnt[block]: the input of k_slab_msg.  Whole workgroup.
+__device__ __forceinline__ void block_message_lists(unsigned char f, uint32_t i, uint32_t blk, uint2* __restrict__ blockcnt,
+                                                    uint32_t* __restrict__ stage_l, uint32_t* __restrict__ stage_r) {
+    __shared__ uint32_t s_cnt[2 * (SL_BLOCK / 64)];
+    const unsigned long long mL = __ballot(f & 1), mR = __ballot(f & 2);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (lane == 0) { s_cnt[2 * w] = __popcll(mL); s_cnt[2 * w + 1] = __popcll(mR); }
+    __syncthreads();
+    uint32_t wl = 0, wr = 0, tl = 0, tr = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SL_BLOCK / 64; ++k) {
+        const uint32_t a = s_cnt[2 * k], b = s_cnt[2 * k + 1];
+        if (k < w) { wl += a; wr += b; }
+        tl += a; tr += b;
+    }
+    if (threadIdx.x == 0) blockcnt[blk] = make_uint2(tl, tr);
+    if (f) {
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        if (f & 1) stage_l[blk * SL_BLOCK + wl + __popcll(mL & below)] = i;
+        if (f & 2) stage_r[blk * SL_BLOCK + wr + __popcll(mR & below)] = i;
+    }
+}
+
 // overlap != 0 (the overlapped step, engine.hip): ghosts never enter the main array, so the slots past `main_slots` are not the
 // unpack area of this step but hold the MIGRANTS the boundary strips received and advanced in the last one (owned flag
 // set by k_strip_writeback); they are carried over like the sorted prefix.
 template <bool COUNTING>
-__global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t cap, uint32_t main_slots, int overlap,
+__global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t cap, uint32_t main_slots, int overlap, int lists,
                                                         int has_left, int has_right, const float2* __restrict__ pos,
                                                         const float2* __restrict__ vel,
                                                         const unsigned char* __restrict__ owned, u64* __restrict__ out /* kt or pairs */,
                                                         uint32_t* __restrict__ hist, uint2* __restrict__ blockcnt,
                                                         uint32_t* __restrict__ stage_l, uint32_t* __restrict__ stage_r,
                                                         uint32_t* __restrict__ counters, uint32_t* __restrict__ gap_counter,
-                                                        unsigned long long* __restrict__ safe) {
-    __shared__ uint32_t s_cnt[2 * (SL_BLOCK / 64)];
+                                                        unsigned long long* __restrict__ safe,
+                                                        const uint32_t* __restrict__ key_prev, uint32_t prev_adv_lo,
+                                                        uint32_t prev_adv_hi) {
     const uint32_t i = blockIdx.x * SL_BLOCK + threadIdx.x;
     if (i == 0) *gap_counter = 0;          // cell-table worklist of this step (bitonic mode: k_slab_reorder)
     if (COUNTING && i < (cap + 63u) / 64u) safe[i] = ~0ull;             // k_cs_fixreorder clears the unsafe bits
@@ -95,23 +120,58 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t c
         base = __shfl(base, r.head_lane);
         if (i < main_slots || (overlap && i < cap)) out[i] = ((u64)key << 32) | (u64)(active ? base + r.offset : 0u);
     }
-    // ---- the slots each message needs, listed per block in slot order
-    const unsigned long long mL = __ballot(f & 1), mR = __ballot(f & 2);
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    if (lane == 0) { s_cnt[2 * w] = __popcll(mL); s_cnt[2 * w + 1] = __popcll(mR); }
-    __syncthreads();
-    uint32_t wl = 0, wr = 0, tl = 0, tr = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < SL_BLOCK / 64; ++k) {
-        const uint32_t a = s_cnt[2 * k], b = s_cnt[2 * k + 1];
-        if (k < w) { wl += a; wr += b; }
-        tl += a; tr += b;
+    if (lists) {
+        block_message_lists(f, i, blockIdx.x, blockcnt, stage_l, stage_r);
+    } else if (f) {
+        // The messages of this step were built at the end of the last one, from the particles its edge-column force launch had
+        // advanced by then (k_slab_prepack).  This full classification flags the same particles — unless one reached the 2-column
+        // band from farther inside than the edge zone (its key of the last step says where it was): then the message that went
+        // out lacks it.  Counted in far_halo (the edge zone was too narrow for its speed: fs_slab_set_boundary_cols).
+        uint32_t cxl, cy;
+        key_to_local(P, key_prev[i], &cxl, &cy);
+        const int32_t cg = (int32_t)cxl + P.col_origin;
+        const bool was_edge = cg >= (int32_t)P.own_lo && cg < (int32_t)P.own_hi && !(cg >= (int32_t)prev_adv_lo && cg < (int32_t)prev_adv_hi);
+        if (!was_edge) atomicAdd(&counters[4], 1u);
     }
-    if (threadIdx.x == 0) blockcnt[blockIdx.x] = make_uint2(tl, tr);
-    if (f) {
-        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-        if (f & 1) stage_l[blockIdx.x * SL_BLOCK + wl + __popcll(mL & below)] = i;
-        if (f & 2) stage_r[blockIdx.x * SL_BLOCK + wr + __popcll(mR & below)] = i;
+}
+
+// Edge-first step (engine.hip): the messages of step t+1 are built at the END of step t, as soon as the force pass
+// has advanced the owned columns within `boundary_cols` of a neighboured edge (StepParams::adv_outside launch) — the exchange
+// then runs beside the force pass of the interior columns and the next step's k_slab_pack.  Same classification, same lists,
+// same slot order as k_slab_pack would produce at t+1 (a particle's sorted index now IS its slot then), restricted to the
+// particles that launch advanced; `P` carries the window and the tick constants the next pack will use.  k_slab_pack (lists
+// = 0) counts what the full classification flags and k_slab_unpack checks it against the headers: a particle that reached the
+// 2-column band from farther inside than the edge zone shows up in far_halo.
+__global__ __launch_bounds__(SL_BLOCK) void k_slab_prepack(StepParams P, int has_left, int has_right, int edge_walk,
+                                                           const float2* __restrict__ pos, const float2* __restrict__ vel,
+                                                           const unsigned char* __restrict__ owned,
+                                                           const uint32_t* __restrict__ key_s, const uint32_t* __restrict__ cs,
+                                                           uint2* __restrict__ blockcnt,
+                                                           uint32_t* __restrict__ stage_l, uint32_t* __restrict__ stage_r) {
+    const uint32_t n = *P.n_live;
+    // edge_walk (column-major ids): a small grid walks the blocks of the edge columns only (fs_device.h EdgeBlocks; k_slab_msg and
+    // k_slab_gather take every other block's counts as zero); otherwise one workgroup per 256-slot block of the whole array
+    EdgeBlocks E;
+    E.eL = 0u; E.eR = 0u; E.nb = gridDim.x;
+    if (edge_walk) E = edge_blocks(P, cs, n, 0u);
+    const uint32_t count = edge_walk ? edge_block_count(E) : gridDim.x;
+    for (uint32_t t = blockIdx.x; t < count; t += gridDim.x) {
+        const uint32_t blk = edge_walk ? edge_block_at(E, t) : t;
+        const uint32_t i = blk * SL_BLOCK + threadIdx.x;
+        unsigned char f = 0;
+        if (i < n && owned[i]) {
+            uint32_t cxl, cy;
+            key_to_local(P, key_s[i], &cxl, &cy);
+            const int32_t cg = (int32_t)cxl + P.col_origin;
+            if (slab_advances(P, cg)) {                     // advanced already: pos / vel hold its new state
+                uint32_t cxg;
+                (void)slab_key(P, predict_pos(P, pos[i], vel[i]), &cxg);
+                if (has_left && cxg < P.own_lo + 2u) f |= 1;
+                if (has_right && cxg + 2u >= P.own_hi) f |= 2;
+            }
+        }
+        block_message_lists(f, i, blk, blockcnt, stage_l, stage_r);
+        __syncthreads();
     }
 }
 
@@ -126,68 +186,82 @@ __device__ __forceinline__ u64 pk_add(u64 a, u64 b) {
 }
 
 #define MSG_GROUP 64u        // pack blocks per k_slab_msg workgroup (one wave scans their counts)
-__global__ __launch_bounds__(SL_BLOCK) void k_slab_msg(uint32_t nblocks_pack, uint32_t R, const uint2* __restrict__ blockcnt,
-                                                       const uint32_t* __restrict__ stage_l, const uint32_t* __restrict__ stage_r,
-                                                       const float2* __restrict__ pos, const float2* __restrict__ vel,
-                                                       u64* __restrict__ state, uint32_t* __restrict__ ticket, uint32_t epoch,
-                                                       SlabHeader* hdr_left, SlabHeader* hdr_right,
-                                                       float4* __restrict__ rec_left, float4* __restrict__ rec_right,
-                                                       uint32_t* __restrict__ counters) {
-    __shared__ uint32_t s_pl[MSG_GROUP + 1], s_pr[MSG_GROUP + 1];      // exclusive prefixes of the group's block counts
+// Round 4: k_slab_msg only turns the per-block counts into per-block message offsets (blockoff) and writes the headers; the
+// records are gathered by k_slab_gather, one workgroup per pack block.  (One kernel did both, each workgroup gathering the
+// records of its 64 blocks: fine while the flagged slots are spread over the whole array — a few per grid row — but with
+// column-major cell ids a rank's edge columns are ~80 CONSECUTIVE blocks per side, i.e. two workgroups gathered 20 000 records
+// each: 50 - 67 us instead of 8.)
+__global__ __launch_bounds__(64) void k_slab_msg(uint32_t nblocks_pack, uint32_t R, const uint2* __restrict__ blockcnt,
+                                                 uint2* __restrict__ blockoff, u64* __restrict__ state,
+                                                 uint32_t* __restrict__ ticket, uint32_t epoch, SlabHeader* hdr_left,
+                                                 SlabHeader* hdr_right, uint32_t* __restrict__ counters, StepParams P,
+                                                 const uint32_t* __restrict__ cs_edge) {
     __shared__ uint32_t s_bid;
-    __shared__ u64 s_excl;
+    // cs_edge != null: only the edge columns' blocks were classified (k_slab_prepack with edge_walk); every other count is zero
+    EdgeBlocks E;
+    E.eL = 0u; E.eR = 0u; E.nb = nblocks_pack;
+    if (cs_edge) E = edge_blocks(P, cs_edge, *P.n_live, 0u);
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t bid = s_bid, ngroups = gridDim.x;
     if (bid == ngroups - 1u && threadIdx.x == 0) *ticket = 0u;          // every ticket of this launch has been handed out
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const uint32_t b0 = bid * MSG_GROUP;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = bid * MSG_GROUP + lane;
     const u64 tag = (u64)(epoch & 0x3FFFFFu);
-    if (w == 0) {
-        const uint32_t b = b0 + lane;
-        const uint2 c = b < nblocks_pack ? blockcnt[b] : make_uint2(0u, 0u);
-        uint32_t il = c.x, ir = c.y;
+    const uint2 c = (b < nblocks_pack && (!cs_edge || edge_block_has(E, b))) ? blockcnt[b] : make_uint2(0u, 0u);
+    uint32_t il = c.x, ir = c.y;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t tx = __shfl_up(il, o), ty = __shfl_up(ir, o);
-            if ((int)lane >= o) { il += tx; ir += ty; }
-        }
-        s_pl[lane + 1u] = il; s_pr[lane + 1u] = ir;                     // inclusive -> exclusive at [lane + 1]
-        if (lane == 0) { s_pl[0] = 0u; s_pr[0] = 0u; }
-        const uint32_t tl = __shfl(il, 63), tr = __shfl(ir, 63);        // <= 64 * 256 each
-        const u64 mine = ((u64)tl << 20) | (u64)tr;
-        if (bid == 0) {
-            if (lane == 0) { lb_store(state, (LB_FLAG_PREFIX << 62) | (tag << 40) | mine); s_excl = 0ull; }
-        } else {
-            if (lane == 0) lb_store(state + bid, (LB_FLAG_AGG << 62) | (tag << 40) | mine);
-            const u64 ex = lookback_exclusive<40>(state, bid, tag, pk_add);
-            if (lane == 0) { lb_store(state + bid, (LB_FLAG_PREFIX << 62) | (tag << 40) | pk_add(ex, mine)); s_excl = ex; }
-        }
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t tx = __shfl_up(il, o), ty = __shfl_up(ir, o);
+        if ((int)lane >= o) { il += tx; ir += ty; }
     }
-    __syncthreads();
-    const u64 ex = s_excl;
+    const uint32_t tl = __shfl(il, 63), tr = __shfl(ir, 63);            // <= 64 * 256 each
+    const u64 mine = ((u64)tl << 20) | (u64)tr;
+    u64 ex = 0ull;
+    if (bid == 0) {
+        if (lane == 0) lb_store(state, (LB_FLAG_PREFIX << 62) | (tag << 40) | mine);
+    } else {
+        if (lane == 0) lb_store(state + bid, (LB_FLAG_AGG << 62) | (tag << 40) | mine);
+        ex = lookback_exclusive<40>(state, bid, tag, pk_add);
+        if (lane == 0) lb_store(state + bid, (LB_FLAG_PREFIX << 62) | (tag << 40) | pk_add(ex, mine));
+    }
     const uint32_t offl = (uint32_t)(ex >> 20), offr = (uint32_t)(ex & PK_FIELD);
-    const uint32_t tl = s_pl[MSG_GROUP], tr = s_pr[MSG_GROUP];
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const uint32_t total = side ? tr : tl, off = side ? offr : offl;
-        const uint32_t* pre = side ? s_pr : s_pl;
-        const uint32_t* stage = side ? stage_r : stage_l;
-        float4* rec = side ? rec_right : rec_left;
-        if (!rec) continue;
-        for (uint32_t r = threadIdx.x; r < total; r += SL_BLOCK) {
-            uint32_t lo = 0, hi = MSG_GROUP;                             // largest pb with pre[pb] <= r
-            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= r) lo = mid; else hi = mid; }
-            const uint32_t slot = stage[(b0 + lo) * SL_BLOCK + (r - pre[lo])];
-            const uint32_t d = off + r;
-            if (d < R) { const float2 p = pos[slot], v = vel[slot]; rec[d] = make_float4(p.x, p.y, v.x, v.y); }
-        }
-    }
-    if (bid == ngroups - 1u && threadIdx.x == 0) {                      // totals: the last group's inclusive prefix
+    if (b < nblocks_pack) blockoff[b] = make_uint2(offl + il - c.x, offr + ir - c.y);      // exclusive offsets of block b's records
+    if (bid == ngroups - 1u && lane == 0) {                             // totals: the last group's inclusive prefix
         const uint32_t totl = offl + tl, totr = offr + tr;              // saturated at 2^20 - 1 > R
         if (hdr_left) { hdr_left->count = totl < R ? totl : R; hdr_left->overflow = totl > R; }
         if (hdr_right) { hdr_right->count = totr < R ? totr : R; hdr_right->overflow = totr > R; }
         if ((hdr_left && totl > R) || (hdr_right && totr > R)) atomicAdd(&counters[3], 1u);
+    }
+}
+
+// The listed records of one pack block -> the two messages, in SLOT order (deterministic).
+__global__ __launch_bounds__(SL_BLOCK) void k_slab_gather(uint32_t R, const uint2* __restrict__ blockcnt,
+                                                          const uint2* __restrict__ blockoff,
+                                                          const uint32_t* __restrict__ stage_l, const uint32_t* __restrict__ stage_r,
+                                                          const float2* __restrict__ pos, const float2* __restrict__ vel,
+                                                          float4* __restrict__ rec_left, float4* __restrict__ rec_right,
+                                                          StepParams P, const uint32_t* __restrict__ cs_edge) {
+    EdgeBlocks E;
+    E.eL = 0u; E.eR = 0u; E.nb = gridDim.x;
+    if (cs_edge) E = edge_blocks(P, cs_edge, *P.n_live, 0u);
+    const uint32_t count = cs_edge ? edge_block_count(E) : gridDim.x;
+    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+        const uint32_t blk = cs_edge ? edge_block_at(E, w) : w;
+        const uint2 c = blockcnt[blk];
+        if ((c.x | c.y) == 0u) continue;
+        const uint2 o = blockoff[blk];
+        const uint32_t t = threadIdx.x;
+        if (rec_left && t < c.x && o.x + t < R) {
+            const uint32_t slot = stage_l[blk * SL_BLOCK + t];
+            const float2 p = pos[slot], v = vel[slot];
+            rec_left[o.x + t] = make_float4(p.x, p.y, v.x, v.y);
+        }
+        if (rec_right && t < c.y && o.y + t < R) {
+            const uint32_t slot = stage_r[blk * SL_BLOCK + t];
+            const float2 p = pos[slot], v = vel[slot];
+            rec_right[o.y + t] = make_float4(p.x, p.y, v.x, v.y);
+        }
     }
 }
 
@@ -278,8 +352,9 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
         const unsigned long long sb = __builtin_amdgcn_ballot_w64(kin_safe(pd, v));   // lanes that returned above: 0
         if ((threadIdx.x & 63u) == 0u) safe[i >> 6] = sb;
     }
-    const uint32_t cy = key / P.grid_w;
-    const int32_t cxg = (int32_t)(key - cy * P.grid_w) + P.col_origin;
+    uint32_t cxl, cy;
+    key_to_local(P, key, &cxl, &cy);
+    const int32_t cxg = (int32_t)cxl + P.col_origin;
     owned[i] = (cxg >= (int32_t)P.own_lo && cxg < (int32_t)P.own_hi) ? 1 : 0;
 
     const uint32_t kc = key < P.ncell ? key : P.ncell;
@@ -313,9 +388,9 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_export(StepParams P, uint32_t
     if (i >= cap) return;
     AosParticle a;
     a.position = pos[i]; a.predicted = pred[i]; a.velocity = vel[i]; a.density = rho[i];
-    const uint32_t k = key[i];
-    const uint32_t cy = k / P.grid_w;
-    a.grid = cy * P.grid_w_global + (uint32_t)((int32_t)(k - cy * P.grid_w) + P.col_origin);
+    uint32_t cxl, cy;
+    key_to_local(P, key[i], &cxl, &cy);
+    a.grid = cy * P.grid_w_global + (uint32_t)((int32_t)cxl + P.col_origin);      // the reference's id (funcs.wgsl:216-218)
     out[i] = a;
 }
 
@@ -347,7 +422,8 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_colhist(StepParams P, const u
     const int32_t cg = (int32_t)c + P.col_origin;
     if (cg < (int32_t)P.own_lo || cg >= (int32_t)P.own_hi) return;
     uint32_t sum = 0;
-    for (uint32_t y = 0; y < P.grid_h; ++y) sum += cs[y * P.grid_w + c + 1] - cs[y * P.grid_w + c];
+    if (P.transposed) sum = cs[(c + 1u) * P.grid_h] - cs[c * P.grid_h];       // a column is one contiguous range of cell ids
+    else for (uint32_t y = 0; y < P.grid_h; ++y) sum += cs[y * P.grid_w + c + 1] - cs[y * P.grid_w + c];
     atomicAdd(&hist_global[cg], sum);       // (the buffer was zeroed; k_slab_colhist_migrants adds to the same words)
 }
 
@@ -361,8 +437,9 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_colhist_migrants(StepParams P
     if (j >= count || !owned[first + j]) return;
     const uint32_t k = key[first + j];
     if (k == FS_DEAD_KEY) return;
-    const uint32_t cy = k / P.grid_w;
-    const int32_t cg = (int32_t)(k - cy * P.grid_w) + P.col_origin;
+    uint32_t cxl, cy;
+    key_to_local(P, k, &cxl, &cy);
+    const int32_t cg = (int32_t)cxl + P.col_origin;
     if (cg >= 0 && cg < (int32_t)P.grid_w_global) atomicAdd(&hist_global[cg], 1u);
 }
 
@@ -553,8 +630,9 @@ __global__ __launch_bounds__(SL_BLOCK) void k_strip_writeback(StepParams P, uint
     const u64 pr = sp_pairs[i];
     const uint32_t k = (uint32_t)(pr >> 32), dst = back[(uint32_t)pr];
     if (dst == STRIP_NONE || k == FS_DEAD_KEY) return;     // a ghost record
-    const uint32_t cy = k / P.grid_w;
-    const int32_t cg = (int32_t)(k - cy * P.grid_w) + P.col_origin;
+    uint32_t cxl, cy;
+    key_to_local(P, k, &cxl, &cy);
+    const int32_t cg = (int32_t)cxl + P.col_origin;
     if (!slab_advances(P, cg)) {
         // interior context (advanced by the interior launch) — or a migrant that landed beyond the boundary zone: nobody
         // advanced it, it is lost (k_strip_unpack has counted it in far_halo already)
@@ -579,11 +657,24 @@ void launch_slab_maxspeed(hipStream_t st, const uint32_t* n_live, const float2* 
     hipLaunchKernelGGL(k_slab_maxspeed, dim3(1024), dim3(SL_BLOCK), 0, st, n_live, vel, owned, out_bits, migr_first, migr_count);
 }
 
+// offsets + headers, then the parallel gather.  blockcnt holds 2 * (blocks + 1) entries: counts, then offsets.
+static void launch_slab_msg(hipStream_t st, uint32_t blocks, uint32_t groups, uint32_t R, void* blockcnt, const uint32_t* stage_l,
+                            const uint32_t* stage_r, const float2* pos, const float2* vel, void* state, uint32_t epoch,
+                            SlabHeader* hl, SlabHeader* hr, uint32_t* counters, const StepParams& P, const uint32_t* cs_edge = nullptr,
+                            uint32_t edge_grid = 0) {
+    uint2* cnt = (uint2*)blockcnt;
+    uint2* off = cnt + (blocks + 1u);
+    hipLaunchKernelGGL(k_slab_msg, dim3(groups), dim3(64), 0, st, blocks, R, (const uint2*)cnt, off, (u64*)state, counters + 6, epoch,
+                       hl, hr, counters, P, cs_edge);
+    hipLaunchKernelGGL(k_slab_gather, dim3(cs_edge ? edge_grid : blocks), dim3(SL_BLOCK), 0, st, R, (const uint2*)cnt, (const uint2*)off,
+                       stage_l, stage_r, pos, vel, hl ? (float4*)(hl + 1) : nullptr, hr ? (float4*)(hr + 1) : nullptr, P, cs_edge);
+}
+
 void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, int has_left,
                       int has_right, const float2* pos, const float2* vel, const unsigned char* owned, u64* out,
                       uint32_t* hist, void* blockcnt, uint32_t* stage /* 2 x capacity words */, void* state, uint32_t epoch,
                       void* msg_left, void* msg_right, uint32_t* counters, uint32_t* gap_counter, unsigned long long* safe,
-                      bool counting, bool overlap) {
+                      bool counting, bool overlap, bool lists, const uint32_t* key_prev, uint32_t prev_adv_lo, uint32_t prev_adv_hi) {
     // covers ALL slots (P.n = capacity): slots past `main_slots` only check for stranded owned particles
     const uint32_t cap = P.n > main_slots ? P.n : main_slots;
     const uint32_t blocks = nb(cap), groups = (blocks + MSG_GROUP - 1u) / MSG_GROUP;
@@ -592,19 +683,34 @@ void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, 
     SlabHeader* hl = (SlabHeader*)msg_left;
     SlabHeader* hr = (SlabHeader*)msg_right;
     if (counting)
-        hipLaunchKernelGGL(k_slab_pack<true>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, overlap ? 1 : 0, has_left, has_right, pos,
-                           vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe);
+        hipLaunchKernelGGL(k_slab_pack<true>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, overlap ? 1 : 0, lists ? 1 : 0, has_left, has_right, pos,
+                           vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe, key_prev, prev_adv_lo, prev_adv_hi);
     else
-        hipLaunchKernelGGL(k_slab_pack<false>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, 0, has_left, has_right, pos,
-                           vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe);
-    if (!hl && !hr) return;                                             // no neighbour: nothing to send
-    hipLaunchKernelGGL(k_slab_msg, dim3(groups), dim3(SL_BLOCK), 0, st, blocks, R, (const uint2*)blockcnt, stage_l, stage_r, pos,
-                       vel, (u64*)state, counters + 6, epoch, hl, hr, hl ? (float4*)(hl + 1) : nullptr,
-                       hr ? (float4*)(hr + 1) : nullptr, counters);
+        hipLaunchKernelGGL(k_slab_pack<false>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, 0, lists ? 1 : 0, has_left, has_right, pos,
+                           vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe, key_prev, prev_adv_lo, prev_adv_hi);
+    if ((!hl && !hr) || !lists) return;                                 // no neighbour / messages pre-built: nothing to send
+    launch_slab_msg(st, blocks, groups, R, blockcnt, stage_l, stage_r, pos, vel, state, epoch, hl, hr, counters, P);
 }
 // words of `stage` and of the look-back state launch_slab_pack needs for `cap` slots
 size_t slab_stage_words(uint32_t cap) { return 2 * (size_t)nb(cap) * SL_BLOCK; }
 size_t slab_msg_groups(uint32_t cap) { return (nb(cap) + MSG_GROUP - 1u) / MSG_GROUP; }
+
+void launch_slab_prepack(hipStream_t st, const StepParams& P_next, uint32_t cap, uint32_t R, int has_left, int has_right,
+                         const float2* pos, const float2* vel, const unsigned char* owned, const uint32_t* key_s, void* blockcnt,
+                         uint32_t* stage, void* state, uint32_t epoch, void* msg_left, void* msg_right, uint32_t* counters,
+                         const uint32_t* cs, uint32_t edge_grid) {
+    const uint32_t blocks = nb(cap), groups = (blocks + MSG_GROUP - 1u) / MSG_GROUP;
+    uint32_t* stage_l = stage;
+    uint32_t* stage_r = stage + (size_t)blocks * SL_BLOCK;
+    SlabHeader* hl = (SlabHeader*)msg_left;
+    SlabHeader* hr = (SlabHeader*)msg_right;
+    if (!hl && !hr) return;
+    const bool walk = edge_grid != 0 && P_next.transposed;
+    hipLaunchKernelGGL(k_slab_prepack, dim3(walk ? edge_grid : blocks), dim3(SL_BLOCK), 0, st, P_next, has_left, has_right, walk ? 1 : 0,
+                       pos, vel, owned, key_s, cs, (uint2*)blockcnt, stage_l, stage_r);
+    launch_slab_msg(st, blocks, groups, R, blockcnt, stage_l, stage_r, pos, vel, state, epoch, hl, hr, counters, P_next,
+                    walk ? cs : nullptr, edge_grid);
+}
 
 void launch_slab_unpack(hipStream_t st, const StepParams& P, uint32_t main_slots, uint32_t R, const void* msg_left,
                         const void* msg_right, float2* pos, float2* vel, u64* out, uint32_t* hist, uint32_t* counters,

@@ -104,10 +104,11 @@ __device__ __forceinline__ uint32_t quirk_lo_fix(const StepParams& P, const u64*
     return v < cnt ? v : cnt;
 }
 
+// (cx, y) are the cell's (u, v) of the handle's id layout (fs_device.h StepParams::transposed; the reference layout: u = x, v = y).
 __device__ __forceinline__ bool row_range(const StepParams& P, const uint32_t* __restrict__ cs, uint32_t cx,
                                           uint32_t y, uint32_t lo_fix, uint32_t* lo, uint32_t* hi) {
-    if (y >= P.grid_h) return false;             // id >= ncell: OOB start_indices read -> nothing
-    const uint32_t id_lo = y * P.grid_w + cx - 1u;
+    if (y >= P.grid_v) return false;             // id >= ncell: OOB start_indices read -> nothing
+    const uint32_t id_lo = y * P.grid_u + cx - 1u;
     if (id_lo >= P.ncell) return false;
     uint32_t id_hi = id_lo + 3u;
     if (id_hi > P.ncell) id_hi = P.ncell;
@@ -154,24 +155,19 @@ __device__ __forceinline__ float density_term(const StepParams& P, float h2, flo
 // TOL (fs_options.math_mode = FS_MATH_TOLERANCE): r2 by one fma, max(h2 - r2, 0) instead of the compare/select, the
 // constant factor mass * 4/(pi h^8) applied once to the sum; stores {pressure_i, 1/rho_i} for the merged force terms.
 template <bool TOL>
-__global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2* __restrict__ pred,
-                                                      const uint32_t* __restrict__ cs,
-                                                      const uint32_t* __restrict__ start_ref,
-                                                      const u64* __restrict__ pairs, const unsigned long long* __restrict__ safe,
-                                                      float* __restrict__ rho_out,
-                                                      float2* __restrict__ rho2_out, uint32_t* __restrict__ force_defer,
-                                                      uint32_t* __restrict__ force_work, uint32_t* __restrict__ force_count) {
-    __shared__ float2 s_pred[3][NB_TILE];
-    __shared__ uint32_t s_red[24];
-    const uint32_t n = P.n_live ? *P.n_live : P.n;
-    uint32_t blk;
-    if (!xcd_block(P, (n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;   // uniform: no live particle in this block
+__device__ __forceinline__ void density_block(const StepParams& P, uint32_t blk, uint32_t n, const float2* __restrict__ pred,
+                                              const uint32_t* __restrict__ cs, const uint32_t* __restrict__ start_ref,
+                                              const u64* __restrict__ pairs, const unsigned long long* __restrict__ safe,
+                                              float* __restrict__ rho_out, float2* __restrict__ rho2_out,
+                                              uint32_t* __restrict__ force_defer, uint32_t* __restrict__ force_work,
+                                              uint32_t* __restrict__ force_count, float2 (*s_pred)[NB_TILE], uint32_t* s_red) {
     const uint32_t i = blk * FS_BLOCK + threadIdx.x;
     const bool live = i < n;
     const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
     const float2 me = pred[live ? i : n - 1];
-    uint32_t cx, cy;
-    xy_local(P, me, &cx, &cy);
+    uint32_t cx, cy;                // (u, v) of the cell-id layout: (x, y) unless the handle is a transposed slab rank
+    int32_t cg;
+    uv_local(P, me, &cx, &cy, &cg);
     const float h2 = P.h * P.h;     // funcs.wgsl:73
     RowRanges R;
 #pragma unroll
@@ -251,6 +247,36 @@ __global__ __launch_bounds__(FS_BLOCK) void k_density(StepParams P, const float2
     // rho >= 0.1; the lean reciprocal is proven correctly rounded on [2^-20, 2^20] (share_div implies that proof)
     const float y = (P.share_div && rho <= FS_RCP_HI) ? rcp_rn_fast(rho) : __fdiv_rn(1.0f, rho);
     rho2_out[i] = make_float2(rho, ok ? y : -y);
+}
+
+#define FS_DENSITY_ARGS                                                                                                   \
+    StepParams P, const float2* __restrict__ pred, const uint32_t* __restrict__ cs, const uint32_t* __restrict__ start_ref, \
+        const u64* __restrict__ pairs, const unsigned long long* __restrict__ safe, float* __restrict__ rho_out,         \
+        float2* __restrict__ rho2_out, uint32_t* __restrict__ force_defer, uint32_t* __restrict__ force_work,            \
+        uint32_t* __restrict__ force_count
+template <bool TOL>
+__global__ __launch_bounds__(FS_BLOCK) void k_density(FS_DENSITY_ARGS) {
+    __shared__ float2 s_pred[3][NB_TILE];
+    __shared__ uint32_t s_red[24];
+    const uint32_t n = P.n_live ? *P.n_live : P.n;
+    uint32_t blk;
+    if (!xcd_block(P, (n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;   // uniform: no live particle in this block
+    density_block<TOL>(P, blk, n, pred, cs, start_ref, pairs, safe, rho_out, rho2_out, force_defer, force_work, force_count, s_pred, s_red);
+}
+// Edge-first slab step, column-major ids (fs_device.h EdgeBlocks): the density of the columns the edge columns' force launch
+// reads — the edge columns and one more towards the interior — ahead of the full launch, on the exchange stream.  (The full
+// launch writes the same values again.)
+template <bool TOL>
+__global__ __launch_bounds__(FS_BLOCK) void k_density_edge(FS_DENSITY_ARGS) {
+    __shared__ float2 s_pred[3][NB_TILE];
+    __shared__ uint32_t s_red[24];
+    const uint32_t n = *P.n_live;
+    const EdgeBlocks E = edge_blocks(P, cs, n, 1u);
+    for (uint32_t t = blockIdx.x; t < edge_block_count(E); t += gridDim.x) {
+        density_block<TOL>(P, edge_block_at(E, t), n, pred, cs, start_ref, pairs, safe, rho_out, rho2_out, force_defer, force_work,
+                           force_count, s_pred, s_red);
+        __syncthreads();                             // the LDS stage is reused
+    }
 }
 
 // ---------------------------------------------------------- force + integrate
@@ -753,11 +779,12 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
     ForceAcc A;
     A.fpx = A.fpy = A.fvx = A.fvy = 0.0f;
     A.seed = ii * 12u + P.frame_time * 69u;                             // compute.wgsl:161
-    uint32_t cx, cy;
-    xy_local(P, me, &cx, &cy);
+    uint32_t cx, cy;                // (u, v) of the cell-id layout: (x, y) unless the handle is a transposed slab rank
+    int32_t cg;
+    uv_local(P, me, &cx, &cy, &cg);
     if (P.n_live) {   // slab mode: ghosts (outside the owned columns) are not advanced, and an overlapped step splits the owned
-                      // columns between the interior launch and the boundary-strip launch (fs_device.h slab_advances)
-        if (!slab_advances(P, (int32_t)cx + P.col_origin)) live = false;
+                      // columns between two launches (fs_device.h slab_advances)
+        if (!slab_advances(P, cg)) live = false;
     }
     RowRanges R;
 #pragma unroll
@@ -871,9 +898,23 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
                      // reference's fragment shader binds (src/simulation.rs:552-559) is written here, no export pass
         AosParticle a;
         a.position = p; a.predicted = me; a.velocity = v; a.density = MODE == 2 ? rho_arr[i] : mrho;
-        a.grid = cy * P.grid_w + cx;      // == the sorted key: same expression as cell_of_point(pred) (single-domain handles only)
+        a.grid = cy * P.grid_u + cx;      // == the sorted key: same expression as cell_of_point(pred) (single-domain handles only)
         aos_out[i] = a;
     }
+}
+
+// Slab ranks with column-major cell ids (StepParams::transposed): a block's 256 consecutive sorted particles span the cell
+// columns [column of its first key, column of its last key].  A launch that advances only the edge columns (or only the interior,
+// fs_device.h slab_advances) leaves every block whose span misses its columns after two scalar loads.
+__device__ __forceinline__ bool block_may_advance(const StepParams& P, const u64* __restrict__ pairs, uint32_t blk, uint32_t n) {
+    if (!P.n_live || !P.transposed) return true;
+    const uint32_t i0 = blk * FS_BLOCK;
+    const uint32_t i1 = (i0 + FS_BLOCK < n ? i0 + FS_BLOCK : n) - 1u;
+    const int32_t cf = (int32_t)((uint32_t)(pairs[i0] >> 32) / P.grid_u) + P.col_origin;
+    const int32_t cl = (int32_t)((uint32_t)(pairs[i1] >> 32) / P.grid_u) + P.col_origin;
+    if (P.adv_outside)
+        return (cf < (int32_t)P.adv_lo && cl >= (int32_t)P.own_lo) || (cl >= (int32_t)P.adv_hi && cf < (int32_t)P.own_hi);
+    return cl >= (int32_t)P.adv_lo && cf < (int32_t)P.adv_hi;
 }
 
 #define FS_FORCE_ARGS                                                                                                  \
@@ -893,8 +934,26 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
     const uint32_t n = P.n_live ? *P.n_live : P.n;
     uint32_t blk;
     if (!xcd_block(P, (n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;   // uniform: no live particle in this block
+    if (!block_may_advance(P, pairs, blk, n)) return;                 // uniform: none of its columns belongs to this launch
     force_block<MODE, AOS, false>(P, blk, n, defer_bits[2u * blk], pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex,
                                   pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
+}
+
+// Edge-first slab step, column-major ids: the lean kernel over the blocks that hold the edge columns only (fs_device.h
+// EdgeBlocks), a small fixed grid walking them.
+template <int MODE, bool AOS>
+__global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FORCE_WAVES, FS_FORCE_WAVES))) void k_force_edge(FS_FORCE_ARGS, uint32_t which) {
+    __shared__ float2 s_pred[3][NBF_ROW];
+    __shared__ uint32_t s_red[24];
+    const uint32_t n = *P.n_live;
+    const EdgeBlocks E = edge_blocks(P, cs, n, 0u);
+    for (uint32_t t = blockIdx.x; t < edge_block_count(E); t += gridDim.x) {
+        const uint32_t blk = edge_block_at(E, t);
+        if (block_may_advance(P, pairs, blk, n))         // uniform (the ghost columns' blocks at the very ends)
+            force_block<MODE, AOS, false>(P, blk, n, defer_bits[2u * blk], pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex,
+                                          pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred, s_red);
+        __syncthreads();                                 // the LDS stage is reused
+    }
 }
 
 // General kernel: a fixed grid walks one of the two worklists with the complete body.
@@ -922,6 +981,7 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_GEN
         const uint32_t* list = worklist + (w ? P.n / FS_BLOCK + 8u : 0u);
         for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
             const uint32_t blk = list[e];
+            if (!block_may_advance(P, pairs, blk, n)) continue;          // uniform
             force_block<MODE, AOS, true>(P, blk, n, defer_bits[2u * blk + w], pos_s, vel_s, pred, rho2, cs, start_ref, pairs,
                                          tex, pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred,
                                          s_red);
@@ -1091,7 +1151,14 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
 
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
                     const uint32_t* start_ref, const u64* pairs, const unsigned long long* safe, float* rho, float2* rho2,
-                    uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count) {
+                    uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count, uint32_t edge_grid) {
+    if (edge_grid) {   // edge-first slab step: the edge columns' blocks only (k_density_edge)
+        if (P.fast_math == 2)
+            hipLaunchKernelGGL(k_density_edge<true>, dim3(edge_grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
+        else
+            hipLaunchKernelGGL(k_density_edge<false>, dim3(edge_grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
+        return;
+    }
     const uint32_t nb = nblk(P.n), grid = xcd_grid(nb, P.xcd_chunk_log2);
     if (P.fast_math == 2)
         hipLaunchKernelGGL(k_density<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
@@ -1103,7 +1170,7 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out, const float* rho_arr, uint32_t* defer_bits, uint32_t* worklist,
                   uint32_t* work_count, void* aos_out, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
-                  uint32_t general_grid, uint32_t* general_hint) {
+                  uint32_t general_grid, uint32_t* general_hint, uint32_t edge_grid) {
     const uint32_t nb = nblk(P.n), grid = xcd_grid(nb, P.xcd_chunk_log2);
 #define FS_LAUNCH_FORCE(K, M, A, G, S, ...)                                                                         \
     hipLaunchKernelGGL((K<M, A>), dim3(G), dim3(FS_BLOCK), 0, S, P, pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex, \
@@ -1125,7 +1192,8 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
         FS_LAUNCH_FORCE_MODE(k_force_general, gg, side, 0u, (uint32_t*)nullptr);
         (void)hipEventRecord(ev_join, side);
     }
-    FS_LAUNCH_FORCE_MODE(k_force, grid, st, 0u);
+    if (edge_grid) FS_LAUNCH_FORCE_MODE(k_force_edge, edge_grid, st, 0u);      // edge-first slab step: the edge columns' blocks only
+    else FS_LAUNCH_FORCE_MODE(k_force, grid, st, 0u);
     if (side) {
         (void)hipStreamWaitEvent(st, ev_join, 0);
         FS_LAUNCH_FORCE_MODE(k_force_general, (nb < 256u ? nb : 256u), st, 1u, (uint32_t*)nullptr);

@@ -285,6 +285,8 @@ typedef struct fs_slab_config {
                                      the serial step (pack -> exchange -> everything) instead of the overlapped one */
 } fs_slab_config;
 #define FS_SLAB_SERIAL 0x100u
+#define FS_SLAB_STRIPS 0x200u
+#define FS_SLAB_ROWMAJOR 0x400u
 
 typedef struct fs_slab_counters {
     uint32_t n_live;        /* live slots after the last step (owned + ghosts; overlapped step: the sorted prefix, i.e. the
