@@ -258,7 +258,13 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # bare `python3 bench.py --gpus N`: this process becomes the launcher.  Nothing here imports torch, loads the
         # HIP library or initialises the GPU; the build (hipcc child processes) happens before any rank exists.
-        if not (args.no_build or under_profiler()):
+        if under_profiler():
+            # the profiler's preloaded library has initialised the GPU in THIS process: starting ranks from it would be the
+            # fork + exec the pool forbids, and none of them would be the profiled program
+            sys.stderr.write("bench.py --gpus N under a profiler: profile one rank directly (set RANK / LOCAL_RANK / WORLD_SIZE / "
+                             "MASTER_ADDR / MASTER_PORT and put `python3 bench.py ...` after `--`), not the launcher\n")
+            raise SystemExit(4)
+        if not args.no_build:
             import __graft_entry__ as ge
             ge._load_build_module().build(verbose=False)
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))

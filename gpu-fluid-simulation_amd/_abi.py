@@ -179,7 +179,7 @@ class MemHandle(C.Structure):
 class SortPlanInfo(C.Structure):
     """fs_sort_plan_info (include/fluidsim.h)."""
     _fields_ = [("shifted", C.c_uint32), ("per_stage", C.c_uint32), ("standby_runs", C.c_uint32), ("stage", C.c_uint32),
-                ("standby_single", C.c_uint32), ("timeouts", C.c_uint32)]
+                ("standby_single", C.c_uint32), ("timeouts", C.c_uint32), ("wide_tiles", C.c_uint32)]
 
 
 # name -> (restype, argtypes).  Every symbol include/fluidsim.h declares.

@@ -701,11 +701,20 @@ fs_status fs_step(fs_sim* s, const fs_tick_settings* t) {
     return enqueue_step(s, t);
 }
 
+// After a synchronisation of the stream: a barrier time-out of the sort's stand-by kernel makes the state undefined from
+// that step on — whoever is about to receive state (or a "finished" signal) must hear about it.
+static fs_status sort_health(fs_sim* s) {
+    if (s->slab || s->opts.sort_mode != FS_SORT_BITONIC) return FS_OK;
+    FS_HIP(s->sortp.check_timeout(s->sort_dirty.p, s->n));
+    if (s->sortp.dead) return fail(FS_ERR_DEVICE, "sort: the stand-by kernel's grid barrier timed out: the particle order is undefined from that step on; destroy the handle");
+    return FS_OK;
+}
+
 fs_status fs_sync(fs_sim* s) {
     if (!s) return fail(FS_ERR_INVALID, "null argument");
     FS_HIP(hipStreamSynchronize(s->stream));
     if (s->comm && s->exch_pending) FS_HIP(hipStreamSynchronize(s->comm));   // an exchange issued but not yet consumed by fs_slab_step
-    return FS_OK;
+    return sort_health(s);
 }
 
 uint32_t fs_tick_count(const fs_sim* s) { return s ? s->tick : 0; }
@@ -766,7 +775,7 @@ fs_status fs_download_particles(fs_sim* s, fs_particle* dst, size_t n) {
     if (r != FS_OK) return r;
     if (n) FS_HIP(hipMemcpyAsync(dst, dev, n * sizeof(fs_particle), hipMemcpyDeviceToHost, s->stream));
     FS_HIP(hipStreamSynchronize(s->stream));
-    return FS_OK;
+    return sort_health(s);        // the records are in `dst` either way (diagnosis); FS_ERR_DEVICE says they are not to be trusted
 }
 
 fs_status fs_upload_particles(fs_sim* s, const fs_particle* src, size_t n) {
@@ -919,7 +928,7 @@ fs_status fs_timed_steps(fs_sim* s, const fs_tick_settings* t, uint32_t steps, d
     float ms = 0.0f;
     FS_HIP(hipEventElapsedTime(&ms, s->t0, s->t1));
     *ms_total = ms;
-    return FS_OK;
+    return sort_health(s);
 }
 
 /* Exhaustive proof used by the force pass: number of f32 x with lo <= |x| <= hi for which the 3-op
@@ -999,7 +1008,7 @@ fs_status fs_sort_plan_read(fs_sim* s, fs_sort_plan_info* out) {
     uint32_t w[8] = {};
     const uint32_t count = s->slab ? s->capacity : s->n;
     if (count > 1) FS_HIP(hipMemcpy(w, s->sort_dirty.p + fsd::sort_plan_word(count), sizeof w, hipMemcpyDeviceToHost));
-    out->shifted = w[1]; out->per_stage = w[2]; out->standby_runs = w[6]; out->timeouts = w[4];
+    out->shifted = w[1]; out->per_stage = w[2]; out->standby_runs = w[6]; out->timeouts = w[4]; out->wide_tiles = w[7];
     out->stage = (uint32_t)s->sortp.stage;
     out->standby_single = (s->sortp.force_single || (s->sortp.stage && s->sortp.trusted >= 2)) ? 1u : 0u;
     return FS_OK;

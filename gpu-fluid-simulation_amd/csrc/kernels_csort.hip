@@ -16,6 +16,7 @@ namespace fsd {
 #define CS_BLOCK 256
 #define CS_ITEMS 16
 #define CS_TILE (CS_BLOCK * CS_ITEMS)
+#define CS_RANK_MAX 2048u    // longest cell segment k_cs_fixreorder still orders by source index (see there)
 
 // ---- pipeline (round 3): 4 launches, no memset, atomics only in the histogram -------------------------------
 //   k_cs_hist        predict + key per particle; per-cell histogram with wave-aggregated atomics.  The value the
@@ -181,7 +182,15 @@ __global__ __launch_bounds__(CS_BLOCK) void k_cs_fixreorder(StepParams P, uint32
     const uint32_t k = key < P.ncell ? key : P.ncell - 1u;
     const uint32_t lo = cs[k], hi = cs[k + 1u];
     uint32_t rank = 0;
-    for (uint32_t q = lo; q < hi; ++q) rank += slot_src[q] < src ? 1u : 0u;
+    if (hi - lo <= CS_RANK_MAX) {
+        for (uint32_t q = lo; q < hi; ++q) rank += slot_src[q] < src ? 1u : 0u;
+    } else {
+        // A cell with more than CS_RANK_MAX particles (a degenerate or uploaded state: thousands of coincident particles, keys
+        // clamped into one cell): the serial rank loop is O(m^2) per cell — 1e5 particles in one cell would be a multi-second
+        // kernel.  Such a cell keeps its ARRIVAL order (p = start + ticket, what k_cs_scatter produced): still
+        // a correct cell sort, no longer independent of the atomics' order inside that one cell.
+        rank = p - lo;
+    }
     const uint32_t d = lo + rank;
     pairs[d] = ((u64)key << 32) | (u64)src;
     const float2 ps = pos_in[src];

@@ -249,9 +249,9 @@ __global__ __launch_bounds__(LT<GB>::THREADS) void k_bitonic_local(u64* __restri
     }
     u64 x[E];
     if (INIT) {
-        // gate == dirty, gate_lo == 2 (launch_bitonic_sort): this launch only serves the tiles the packed kernel
+        // gate_lo == 2 with no gate (launch_bitonic_sort): this launch only serves the tiles the packed kernel
         // (k_bitonic_local32) could not take — their flag is FS_TILE_WIDE; anything else returns at once
-        if (gate_lo == FS_TILE_WIDE && gate && gate[blockIdx.x] != FS_TILE_WIDE) return;
+        if (gate_lo == FS_TILE_WIDE && dirty[blockIdx.x] != FS_TILE_WIDE) return;
         if (KEYGEN != 0 && blockIdx.x == 0 && t == 0) *gap_counter = 0;      // consumed by k_reorder later in the stream
         // coalesced load, straight into LDS, then the group-0 view
 #pragma unroll
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(LT<GB>::THREADS) FS_SORT32_ATTR void k_bitonic_loca
                                                                      uint32_t num_stages, uint32_t* __restrict__ dirty,
                                                                      StepParams P, const float2* __restrict__ pos,
                                                                      const float2* __restrict__ vel,
-                                                                     uint32_t* __restrict__ gap_counter) {
+                                                                     uint32_t* __restrict__ gap_counter, uint32_t wide_word) {
     constexpr int E = LT<GB>::E;
     __shared__ uint32_t s[LT<GB>::LDS];
     __shared__ uint32_t s_mm[2 * (LT<GB>::THREADS / 64)];
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(LT<GB>::THREADS) FS_SORT32_ATTR void k_bitonic_loca
     }
     static_assert(KEYGEN == 1 || KEYGEN == 2, "the packed form builds the pairs itself: index = base + position");
     if (kmax - kmin >= (1u << 20) - 1u) {                                // uniform; 0xFFFFF is reserved for the padding
-        if (t == 0) dirty[blockIdx.x] = FS_TILE_WIDE;
+        if (t == 0) { dirty[blockIdx.x] = FS_TILE_WIDE; atomicAdd(&dirty[wide_word], 1u); }   // (counted: fs_sort_plan_info.wide_tiles)
         return;
     }
     uint32_t x[E];
@@ -852,10 +852,10 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
     static const bool packed = [] { const char* e = getenv("FS_SORT_PACKED"); return e ? atoi(e) != 0 : true; }();
 #define FS_LAUNCH_INIT32(KG, GBV, PP, POS, VEL, GC)                                                                      \
     hipLaunchKernelGGL((k_bitonic_local32<KG, GBV>), dim3(tiles), dim3(LT<GBV>::THREADS), 0, st, pairs, n, init_stages,   \
-                       dirty, PP, POS, VEL, GC)
+                       dirty, PP, POS, VEL, GC, sort_plan_word(n) + 7u)
 #define FS_LAUNCH_INIT_WIDE(KG, GBV, PP, POS, VEL, GC)                                                                   \
     hipLaunchKernelGGL((k_bitonic_local<true, KG, GBV>), dim3(tiles), dim3(LT<GBV>::THREADS), 0, st, pairs, n, init_stages, \
-                       dirty, PP, POS, VEL, GC, (const uint32_t*)dirty, FS_TILE_WIDE, 0u)
+                       dirty, PP, POS, VEL, GC, (const uint32_t*)nullptr, FS_TILE_WIDE, 0u)
     if (keygen) {
         if (packed) {
             if (gb == 3) { FS_LAUNCH_INIT32(1, 3, *keygen, pos, vel, gap_counter); FS_LAUNCH_INIT_WIDE(1, 3, *keygen, pos, vel, gap_counter); }

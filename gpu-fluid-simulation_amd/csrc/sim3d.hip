@@ -1270,7 +1270,13 @@ fs_status fs3_step(fs_sim3* s, const fs3_tick_settings* t) {
     H3(hipSetDevice(s->device));
     return enqueue3(s, t);
 }
-fs_status fs3_sync(fs_sim3* s) { if (!s) return fail3(FS_ERR_INVALID, "null"); H3(hipStreamSynchronize(s->stream)); return FS_OK; }
+// a barrier time-out of the sort's stand-by kernel leaves the particle order undefined: reported wherever state is handed over
+static fs_status sort_health3(fs_sim3* s) {
+    H3(s->sortp.check_timeout(s->dirty.p, s->n));
+    if (s->sortp.dead) return fail3(FS_ERR_DEVICE, "sort: the stand-by kernel's grid barrier timed out: the particle order is undefined from that step on; destroy the handle");
+    return FS_OK;
+}
+fs_status fs3_sync(fs_sim3* s) { if (!s) return fail3(FS_ERR_INVALID, "null"); H3(hipStreamSynchronize(s->stream)); return sort_health3(s); }
 uint32_t fs3_tick_count(const fs_sim3* s) { return s ? s->tick : 0; }
 uint32_t fs3_particle_count(const fs_sim3* s) { return s ? s->n : 0; }
 fs_status fs3_grid_dims(const fs_sim3* s, uint32_t* w, uint32_t* h, uint32_t* d) {
@@ -1286,7 +1292,7 @@ fs_status fs3_download_particles(fs_sim3* s, fs3_particle* dst, size_t n) {
                        s->vel.p, s->key.p, s->aos.p);
     if (n) H3(hipMemcpyAsync(dst, s->aos.p, n * sizeof(fs3_particle), hipMemcpyDeviceToHost, s->stream));
     H3(hipStreamSynchronize(s->stream));
-    return FS_OK;
+    return sort_health3(s);
 }
 fs_status fs3_upload_particles(fs_sim3* s, const fs3_particle* src, size_t n) {
     if (!s || (!src && n)) return fail3(FS_ERR_INVALID, "null argument");
@@ -1309,7 +1315,7 @@ fs_status fs3_timed_steps(fs_sim3* s, const fs3_tick_settings* t, uint32_t steps
     float ms = 0;
     H3(hipEventElapsedTime(&ms, s->t0, s->t1));
     *ms_total = ms;
-    return FS_OK;
+    return sort_health3(s);
 }
 fs_status fs3_profile_enable(fs_sim3* s, int enable) { if (!s) return fail3(FS_ERR_INVALID, "null"); s->profile = enable != 0; return FS_OK; }
 fs_status fs3_profile_read(fs_sim3* s, double ms[FS_PASS_COUNT], uint64_t* steps, int reset) {

@@ -105,16 +105,30 @@ struct SortPolicy {
     }
     uint32_t* general_hint() const { return fb ? fb + 6 : nullptr; }
 
+    // After a synchronisation of the simulation's stream: did the stand-by kernel (k_late_fallback) report a grid-barrier
+    // time-out in any of the steps enqueued so far?  From that step on the particle order is undefined (include/fluidsim.h), so
+    // every call that hands state to the caller checks this — not only the plan() of a later step.  `dirty`: the sort's tile
+    // flags of `n` elements (the plan words behind them hold the count).  Latches.
+    bool dead = false;
+    hipError_t check_timeout(const uint32_t* dirty, uint32_t n) {
+        if (dead || !enabled || n < (1u << 15)) return hipSuccess;
+        uint32_t t = 0;
+        const hipError_t r = hipMemcpy(&t, dirty + sort_plan_word(n) + 4, sizeof t, hipMemcpyDeviceToHost);
+        if (r == hipSuccess && t) dead = true;
+        return r;
+    }
+
     // The plan of this step's sort of n elements.  Returns false when the stand-by kernel reported a barrier time-out.
     bool plan(uint32_t n, SortPlan* out) {
         uint32_t S = 0;
         while ((1u << S) < n) ++S;
         out->fuse_stage = fixed_stage; out->fallback = (force_single && fixed_stage > 0) ? 1 : 0; out->feedback = nullptr; out->seq = 0;
+        if (dead) return false;
         if (!enabled || !fb || S < 15) return true;
         const volatile uint32_t* f = fb;
         const uint32_t s = f[0];
         if (s != seen) {
-            if (f[4]) return false;
+            if (f[4]) { dead = true; return false; }
             observe(s, (int)f[1], f[2] != FS_SORT_NO_PLAN, (int)f[3], S);
         }
         out->fuse_stage = stage ? stage : first_stage(S);

@@ -377,7 +377,10 @@ class SlabDriver:
     def rebalance(self):
         dist = self.t.dist
         c = {}
-        if hasattr(self.e, "rebalance_inputs"):                  # device-resident engine: two all-reduces, ONE host read
+        # device-resident engine: two all-reduces, ONE host read.  FS_REBALANCE_HOST=1 keeps the older path (three blocking
+        # reads + two all-reduces of host arrays); the torch-nccl and the fs_comm_allreduce branches of rebalance_inputs have
+        # only ever run single-rank (no multi-GPU box): tests/test_multi_gpu.py compares the two paths over gloo, world 2
+        if hasattr(self.e, "rebalance_inputs") and not os.environ.get("FS_REBALANCE_HOST"):
             hist, stats = self.e.rebalance_inputs(self.grid_w)
             if not self.check_counters:
                 stats[:3] = 0
@@ -585,11 +588,18 @@ def bench_main(args, rank, local_rank, world):
                          "step_aggregate": {"alg_bytes_per_particle": ALG_TOTAL, "achieved": round(agg, 1),
                                             "peak": HBM_PEAK_GBS * world, "frac": round(agg / (HBM_PEAK_GBS * world), 4)}},
             "checks": {"particles_conserved": int(nlive.item()) == n, "protocol_violations": int(bad.item())},
+            "slab_step": {0: "serial (pack -> exchange -> step)", 1: "edge-first (next step's messages built and exchanged beside the interior "
+                          "columns' force pass; column-major cell ids on ranks with neighbours)", 2: "strips (interior while the messages "
+                          "fly, boundary strips afterwards)"}[eng.sim.step_mode],
+            "boundary_cols": drv.last_boundary,
             # like-for-like base of the scaling curve: N = 1 of bench.py runs the PLAIN engine with the reference
             # network; this is the SAME slab engine (counting sort, fixed-capacity slots, pack/unpack) as ONE rank
             "scaling_base": base,
             "multi_gpu_note": "8-GPU timing is produced by the driver's SCALE run only; this builder's boxes have one GPU",
         }
+        if not args.no_cpu_baseline:     # rank 0, after the timed region (the other ranks wait in the barrier below)
+            from bench import cpu_baseline
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -80,7 +80,7 @@ pub const EXPORT_START_INDICES: c_int = 1;
 
 /// fs_sort_plan_info: diagnostics of the sort's late-stage plan.
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]
-pub struct SortPlanInfo { pub shifted: u32, pub per_stage: u32, pub standby_runs: u32, pub stage: u32, pub standby_single: u32, pub timeouts: u32 }
+pub struct SortPlanInfo { pub shifted: u32, pub per_stage: u32, pub standby_runs: u32, pub stage: u32, pub standby_single: u32, pub timeouts: u32, pub wide_tiles: u32 }
 
 /// fs_slab_config / fs_slab_counters (multi-GPU slabs; not in the reference).
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]

@@ -465,6 +465,8 @@ typedef struct fs_sort_plan_info {
     uint32_t stage;          /* first stage the shifted merge currently replaces (0: engine default) */
     uint32_t standby_single; /* 1: the single stand-by launch is in use instead of the per-stage launches */
     uint32_t timeouts;       /* stand-by grid-barrier time-outs (0 on a healthy device) */
+    uint32_t wide_tiles;     /* 4096-element tiles whose keys spanned >= 2^20 - 1 cells (an uploaded, unordered state on a large grid):
+                                left by the packed first kernel to the 64-bit one */
 } fs_sort_plan_info;
 fs_status fs_sort_plan_read(fs_sim* sim, fs_sort_plan_info* out);
 

@@ -176,6 +176,30 @@ def test_3d_8m_full_state_matches_oracle(fs, orc):
 
 
 @pytest.mark.gpu
+def test_3d_shuffled_upload_takes_the_wide_tile_path(fs, orc):
+    """The same hand-over in 3D: the 8M scene's grid has 402 x 252 x 204 = 20.7M cells, so a permuted upload makes
+    every 4096-element tile of the first sort kernel wide; the step after it must still equal the 3D oracle bit for bit."""
+    import bench
+    n = 200 ** 3
+    st, off, tick = fs.dam_break_3d(n)
+    sim = fs.FluidSimulation3D(st, device=0, initial_offset=off)
+    p = sim.download_particles()
+    p = p[np.random.default_rng(6).permutation(n)]
+    sim.upload_particles(p)
+    sim.tick(tick)
+    got = sim.download_particles()
+    sim.close()
+    orc.set_threads(min(bench.usable_cores(), orc.max_threads()))
+    try:
+        ref = orc.OracleSim3D(st, off)
+        ref.set_particles(p)
+        ref.step(tick)
+        _assert_equal3(got, ref.particles_view(), "3d 8M step 1 after a shuffled upload")
+    finally:
+        orc.set_threads(1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("side,seed,pre", [(16, None, 0), (24, 7, 3), (33, 9, 10), (12, 2, 0)])
 def test_3d_tolerance_mode_within_tolerance(fs, orc, side, seed, pre):
     """fs3_create_ex(FS_MATH_TOLERANCE): one step from an identical state against the 3D oracle — cell keys bit-exact

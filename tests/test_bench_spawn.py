@@ -67,6 +67,17 @@ def test_bench_parent_branch_is_before_any_gpu_import():
     assert "os.exec" not in src and "execv" not in src
 
 
+def test_launcher_refuses_to_spawn_under_a_profiler():
+    """under rocprofv3 the preloaded library has initialised the GPU in the parent; a bare `--gpus N` must not start
+    ranks from it (fork + exec from a GPU process), it exits 4 with a message instead."""
+    env = dict(os.environ, ROCPROF_TEST_MARKER="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 4 and "under a profiler" in r.stderr and not r.stdout.strip()
+
+
 @pytest.mark.gpu
 def test_bare_bench_gpus2_runs_to_a_parsed_line():
     """`python3 bench.py --gpus 2` with no launcher: two ranks share the one GPU of the box over gloo."""
@@ -84,3 +95,4 @@ def test_bare_bench_gpus2_runs_to_a_parsed_line():
     assert "rank0_passes_ms" in out["roofline"]
     # the roofline's kernel is a compute pass; the pack + exchange interval is reported beside it, never as "the kernel"
     assert not out["roofline"]["kernel"].startswith("predict_key") and out["roofline"]["pack_exchange_ms"] > 0
+    assert out["slab_step"].startswith("edge-first") and out["boundary_cols"] >= 4

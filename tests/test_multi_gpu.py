@@ -563,3 +563,59 @@ def test_edge_zone_narrower_than_the_travel_is_counted(fs):
         c = sim.counters()
         assert (c["far_halo"] == 0) == clean, (cols, c)
         sim.close()
+
+
+REBALANCE_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import gpu_fluid_simulation_amd as g
+from gpu_fluid_simulation_amd import multi
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 65536
+st, off, tick = g.dam_break_2d(n)
+hist, gw = multi.lattice_histogram(g, st, off)
+gh = int(np.ceil(np.float32(st.size.y) / np.float32(st.smoothing_radius))) + 2
+bounds = multi.partition_columns(hist, world)
+cap, recv = multi.slab_capacities(n, world, gh)
+tr = multi.Transport(rank, world, multi.HEADER_BYTES + multi.RECORD_BYTES * recv)
+eng = multi.HipSlabEngine(g, st, bounds, rank, world, cap, recv, gw, 0, tr)
+eng.sim.upload_owned(multi.initial_owned(g, st, off, bounds, rank))
+drv = multi.SlabDriver(eng, tr, bounds, gw, rebalance_every=0)
+for _ in range(7):
+    drv.step(tick)
+eng.sync()
+# the device-resident path: fs_slab_rebalance_stats + two all-reduces + ONE read ...
+h_dev, s_dev = eng.rebalance_inputs(gw)
+# ... against the host path it replaced: three blocking reads, two all-reduces of host arrays
+h_host = torch.from_numpy(eng.column_histogram(gw).astype(np.int64)); dist.all_reduce(h_host)
+c = eng.counters()
+s_host = torch.tensor([c["lost"], c["overflow"], c["far_halo"], float(eng.max_speed())], dtype=torch.float64)
+dist.all_reduce(s_host, op=dist.ReduceOp.MAX)
+assert np.array_equal(h_dev, h_host.numpy()), "column histograms differ"
+assert int(h_dev.sum()) == n, int(h_dev.sum())
+assert np.array_equal(s_dev[:3], s_host.numpy()[:3]) and np.float32(s_dev[3]) == np.float32(s_host.numpy()[3]), (s_dev, s_host)
+assert s_dev[3] > 0
+# and the driver's two ways of re-balancing move the boundaries identically
+b0 = list(drv.bounds)
+drv.rebalance_every = 1; drv.rebalance(); via_dev = list(drv.bounds)
+dist.barrier()
+print("rebalance paths agree", rank, b0, via_dev, flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_rebalance_inputs_equal_the_host_path_world2(fs, tmp_path):
+    """HipSlabEngine.rebalance_inputs (device buffers, all-reduce, one read) against the column_histogram + counters +
+    max_speed + host all-reduce path it replaced, with TWO ranks (gloo, both on this GPU): identical histogram (summing to every
+    particle), identical violation counters and largest speed.  Its torch-nccl and fs_comm_allreduce branches need N GPUs and
+    stay unverified on hardware."""
+    script = tmp_path / "reb_worker.py"
+    script.write_text(REBALANCE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), cwd=ROOT, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert all("rebalance paths agree" in o for o in outs)

@@ -288,6 +288,62 @@ def test_16m_full_state_matches_oracle(fs, orc):
     sim.close()
 
 
+def test_shuffled_upload_on_a_large_grid_takes_the_wide_tile_path(fs, orc):
+    """the packed first sort kernel (k_bitonic_local32) leaves a 4096-element tile whose keys span >= 2^20 - 1 cells to
+    the 64-bit kernel that follows (FS_TILE_WIDE).  That needs a grid of more than a million cells AND an unordered state — an
+    fs_upload_particles of a permuted state at 4M particles (2050 x 1282 = 2.6M cells).  Every tile is then wide; the step must
+    still be bit for bit the oracle's (keys, every field, start_indices), also in the step after."""
+    import bench
+    n = 1 << 22
+    st, off, tick = fs.dam_break_2d(n)
+    sim = fs.FluidSimulation(st, device=0, initial_offset=off)
+    orc.set_threads(min(bench.usable_cores(), orc.max_threads()))
+    try:
+        ref = orc.OracleSim(st, off)
+        for _ in range(2):
+            sim.tick(tick); ref.step(tick)
+        assert sim.sort_plan()["wide_tiles"] == 0                # a state in cell order: no tile spans that much
+        p = sim.download_particles()
+        p = p[np.random.default_rng(5).permutation(n)]
+        sim.upload_particles(p); ref.set_particles(p)
+        for step in (1, 2):
+            sim.tick(tick); ref.step(tick)
+            got, want = sim.download_particles(), ref.particles_view()
+            assert np.array_equal(got["grid"], want["grid"]), f"step {step} after the shuffled upload: cell keys differ"
+            for f in ("position", "predicted_position", "velocity", "density"):
+                assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f"step {step}: {f} not bit-exact"
+            assert np.array_equal(sim.download_start_indices(), ref.start_indices_view())
+            if step == 1:
+                assert sim.sort_plan()["wide_tiles"] >= n // 4096 // 2, sim.sort_plan()
+    finally:
+        orc.set_threads(1)
+    sim.close()
+
+
+def test_counting_sort_survives_a_cell_with_30k_particles(fs):
+    """k_cs_fixreorder ranks a slot inside its cell segment with a serial loop — O(m^2) for a cell of m particles, on top
+    of the m^2 pairs the force pass must visit anyway (which is why this test stops at 30 000 coincident particles, ~1e9 pairs).
+    Segments above 2048 now keep their arrival order.  The step must finish with a valid arrangement (keys sorted, nothing lost,
+    finite predicted positions)."""
+    import time
+    n = 1 << 18
+    st, off, tick = fs.dam_break_2d(n)
+    sim = fs.FluidSimulation(st, device=0, initial_offset=off, sort_mode=fs.FS_SORT_COUNTING, ref_quirks=False)
+    p = sim.download_particles()
+    p["position"][:30_000] = p["position"][0]
+    p["predicted_position"][:30_000] = p["position"][0]
+    sim.upload_particles(p)
+    t0 = time.perf_counter()
+    sim.tick(tick)
+    q = sim.download_particles()
+    assert time.perf_counter() - t0 < 30.0
+    assert np.all(q["grid"][:-1] <= q["grid"][1:])
+    cell, cnt = np.unique(q["grid"], return_counts=True)
+    assert cnt.max() >= 30_000 and q.shape[0] == n
+    assert np.isfinite(q["predicted_position"]).all()
+    sim.close()
+
+
 def test_16m_properties(fs):
     """Size-independent properties at the headline size: sortedness, start_indices
     consistency, permutation (multiset of lattice x-coordinates preserved), finite state."""

@@ -183,6 +183,26 @@ def test_a_barrier_time_out_report_kills_the_handle(fs, monkeypatch):
     rng = np.random.default_rng(11)
     p = sim.download_particles()
     sim.upload_particles(p[rng.permutation(n)])           # an arbitrary order: the certificate fails, the stand-by kernel works
+    # a caller that steps, synchronises and downloads must not get FS_OK and a corrupt state — the time-out is
+    # reported by the FIRST synchronisation after the offending step, not only by the plan of a later fs_step
+    sim.tick(tick)                                        # the stand-by kernel runs (and "times out") in this very step
+    with pytest.raises(fs.FluidSimError) as ei:
+        sim.sync()
+    assert ei.value.status == fs._abi.FS_ERR_DEVICE and "timed out" in str(ei.value)
+    with pytest.raises(fs.FluidSimError):
+        sim.download_particles()
+    info = sim.sort_plan()                                # diagnostics stay readable
+    assert info["timeouts"] >= 1 and info["standby_runs"] >= 1
+    for _ in range(3):                                    # terminal: every later step fails the same way
+        with pytest.raises(fs.FluidSimError) as ei:
+            sim.tick(tick)
+        assert ei.value.status == fs._abi.FS_ERR_DEVICE
+    del sim
+    # ... and when nobody synchronises in between, the certificate's report of a LATER step stops the run as before
+    monkeypatch.setenv("FS_SORT_TRUST", "1"); monkeypatch.setenv("FS_SORT_INJECT_TIMEOUT", "1")
+    sim = fs.FluidSimulation(st, device=0, initial_offset=off)
+    monkeypatch.delenv("FS_SORT_TRUST"); monkeypatch.delenv("FS_SORT_INJECT_TIMEOUT")
+    sim.upload_particles(p[rng.permutation(n)])
     failed_at = None
     for i in range(30):
         try:
@@ -191,14 +211,7 @@ def test_a_barrier_time_out_report_kills_the_handle(fs, monkeypatch):
             assert e.status == fs._abi.FS_ERR_DEVICE and "timed out" in str(e)
             failed_at = i
             break
-    assert failed_at is not None and failed_at >= 1       # reported by the certificate of a LATER step
-    info = sim.sort_plan()
-    assert info["timeouts"] >= 1 and info["standby_runs"] >= 1
-    for _ in range(3):                                    # terminal: every later step fails the same way
-        with pytest.raises(fs.FluidSimError) as ei:
-            sim.tick(tick)
-        assert ei.value.status == fs._abi.FS_ERR_DEVICE
-    sim.download_particles()                              # reading the state back still works (diagnosis)
+    assert failed_at is not None and failed_at >= 1
     del sim
     other = fs.FluidSimulation(st, device=0, initial_offset=off)       # a fresh handle is healthy
     for _ in range(5):
