@@ -116,6 +116,7 @@ struct fs_sim {
     bool key_in_pairs = false;
     bool rho_in_rho2 = false;       // likewise the densities: rho2.x after a strict / ulp step, `rho` after an upload or a tolerance step
     DevArray<uint32_t> fdefer, fwork;   // force pass: per-block deferred-wave bits and the worklist (counter[3] = its length)
+    DevArray<uint32_t> bbounds;         // 8 words per 256-particle block: the density pass's block-wide sweep ranges, read by the force pass
     DevArray<unsigned long long> safe;   // one bit per sorted particle: coordinates / velocity inside the exact-quotient ranges (fs_device.h)
     DevArray<fsd::u64> pairs;
     DevArray<uint32_t> sort_dirty;  // per-tile flags of the bitonic sort
@@ -177,14 +178,14 @@ struct fs_sim {
         DevArray<float2> pos, vel, pos_s, vel_s, pred, rho2, pos_out, vel_out;
         DevArray<float> rho;
         DevArray<fsd::u64> pairs;
-        DevArray<uint32_t> csort, cs, start_ref, fdefer, fwork, counter, back, rowbase, counters;
+        DevArray<uint32_t> csort, cs, start_ref, fdefer, fwork, counter, back, rowbase, counters, bbounds;
         DevArray<unsigned long long> safe;
         DevArray<unsigned char> owned;
         uint32_t cap = 0;
         void release() {
             pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho2.release(); pos_out.release();
             vel_out.release(); rho.release(); pairs.release(); csort.release(); cs.release(); start_ref.release(); fdefer.release();
-            fwork.release(); counter.release(); back.release(); rowbase.release(); counters.release(); safe.release(); owned.release();
+            fwork.release(); counter.release(); back.release(); rowbase.release(); counters.release(); safe.release(); owned.release(); bbounds.release();
         }
     } strip;
 
@@ -200,7 +201,7 @@ struct fs_sim {
 
     void release() {
         pos.release(); vel.release(); pos_s.release(); vel_s.release(); pred.release(); rho.release(); rho2.release();
-        key.release(); safe.release(); fdefer.release(); fwork.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
+        key.release(); safe.release(); fdefer.release(); fwork.release(); bbounds.release(); pairs.release(); sort_dirty.release(); csort.release(); cs.release(); start_ref.release(); tex.release(); work.release();
         counter.release(); aos.release();
         owned.release(); blockcnt.release(); stage.release(); msg_state.release(); slab_counters.release();
         hist.release(); strip.release();
@@ -338,6 +339,8 @@ fsd::StepParams make_params(const fs_sim& s) {
     }
     P.grid_u = P.transposed ? P.grid_h : P.grid_w;
     P.grid_v = P.transposed ? P.grid_w : P.grid_h;
+    static const bool no_bb = getenv("FS_NO_BLOCK_BOUNDS") != nullptr;      // A/B: every pass reduces its block bounds itself
+    P.block_bounds = no_bb ? nullptr : s.bbounds.p;
     return P;
 }
 
@@ -490,7 +493,7 @@ fsd::StepParams overlap_params(const fs_sim& s, bool strip) {
     fsd::StepParams P = make_params(s);
     P.adv_lo = s.adv_lo; P.adv_hi = s.adv_hi;
     P.adv_outside = strip ? 1 : 0;
-    if (strip) { P.n = s.strip.cap; P.n_live = s.strip.counters.p; }
+    if (strip) { P.n = s.strip.cap; P.n_live = s.strip.counters.p; if (P.block_bounds) P.block_bounds = s.strip.bbounds.p; }
     return P;
 }
 
@@ -645,7 +648,7 @@ fs_status fs_create_ex(const fs_settings* settings, const fs_options* opts, fs_s
     }
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc((cap + 63) / 64 + 1)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc((cap + 63) / 64 + 1)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->bbounds.alloc(8 * ((cap + 255) / 256 + 8))); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->cs.alloc((size_t)s->ncell + 1));
@@ -1159,7 +1162,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
     FS_TRY(s->sortp.init(8));   // slab handles use the pinned words for the force pass's work report only (sort: per-stage plan)
     const size_t cap = s->capacity;
     FS_TRY(s->pos.alloc(cap)); FS_TRY(s->vel.alloc(cap)); FS_TRY(s->pos_s.alloc(cap)); FS_TRY(s->vel_s.alloc(cap));
-    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc((cap + 63) / 64 + 1)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->pairs.alloc(cap));
+    FS_TRY(s->pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(s->rho.alloc(cap)); FS_TRY(s->rho2.alloc(cap)); FS_TRY(s->key.alloc(cap)); FS_TRY(s->safe.alloc((cap + 63) / 64 + 1)); FS_TRY(s->fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(s->fwork.alloc(2 * (cap / 256 + 8) + 16)); FS_TRY(s->bbounds.alloc(8 * ((cap + 255) / 256 + 8))); FS_TRY(s->pairs.alloc(cap));
     FS_TRY(s->sort_dirty.alloc(fsd::sort_tile_count((uint32_t)cap)));
     FS_TRY(hipMemsetAsync(s->sort_dirty.p, 0, s->sort_dirty.n * sizeof(uint32_t), s->stream));
     FS_TRY(s->owned.alloc(cap));
@@ -1196,6 +1199,7 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
         FS_TRY(T.pred.alloc(cap + FS_PRED_SLACK)); FS_TRY(T.rho2.alloc(cap)); FS_TRY(T.pos_out.alloc(cap)); FS_TRY(T.vel_out.alloc(cap));
         FS_TRY(T.rho.alloc(cap)); FS_TRY(T.pairs.alloc(cap)); FS_TRY(T.safe.alloc((cap + 63) / 64 + 1)); FS_TRY(T.owned.alloc(cap));
         FS_TRY(T.fdefer.alloc(2 * ((cap + 255) / 256 + 8))); FS_TRY(T.fwork.alloc(2 * (cap / 256 + 8) + 16));
+        FS_TRY(T.bbounds.alloc(8 * ((cap + 255) / 256 + 8)));
         FS_TRY(T.csort.alloc(fsd::counting_sort_scratch_words((uint32_t)cap, s->ncell)));
         FS_TRY(hipMemsetAsync(T.csort.p, 0, T.csort.n * sizeof(uint32_t), s->stream));
         FS_TRY(T.cs.alloc((size_t)s->ncell + 1)); FS_TRY(T.start_ref.alloc(s->ncell));

@@ -63,6 +63,11 @@ struct StepParams {
     // hundred whole blocks at the two ends of the sorted array instead of a few lanes of every grid row.
     uint32_t grid_u, grid_v;
     int32_t transposed;
+    // --- density -> force hand-off per 256-particle block (8 words each): the block-wide candidate ranges of the three sweep rows
+    // [lo0, lo1, lo2, hi0, hi1, hi2] as block_tile_bounds() reduces them from the lanes' row ranges.  Both passes sweep the
+    // same rows, so the force pass reads the density pass's result (eight scalar loads) instead of repeating the reduction
+    // (ballots, readlanes, an LDS round trip and a barrier).  nullptr: every pass reduces for itself.
+    uint32_t* block_bounds;
 };
 
 // Slab mode: does the force pass of this launch advance a particle whose GLOBAL cell column is cg?  (Ghosts — columns outside

@@ -178,6 +178,10 @@ __device__ __forceinline__ void density_block(const StepParams& P, uint32_t blk,
     }
     uint32_t blo[3], bhi[3];
     const bool fit = block_tile_bounds(R, s_red, blo, bhi, NB_TILE);
+    if (P.block_bounds && threadIdx.x == 0) {       // the force pass reads these instead of reducing the same ranges again
+        uint32_t* bb = P.block_bounds + 8u * blk;
+        bb[0] = blo[0]; bb[1] = blo[1]; bb[2] = blo[2]; bb[3] = bhi[0]; bb[4] = bhi[1]; bb[5] = bhi[2];
+    }
     {   // The force pass sweeps the same row ranges: a wave it could not finish on its lean path — a row longer than
         // 32 candidates, or a block whose rows do not fit ITS LDS stage — is named here already, so that the general
         // workgroups of the force launch can start on it at once, beside the lean ones (k_force).
@@ -794,7 +798,16 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
         if (R.hi[r] < R.lo[r]) R.hi[r] = R.lo[r];
     }
     uint32_t blo[3], bhi[3];
-    const bool staged = block_tile_bounds(R, s_red, blo, bhi, NBF_TILE);
+    bool staged;
+    if (P.block_bounds) {
+        // the density pass of this step reduced the same ranges over the same 256 particles (a slab launch that advances only
+        // some columns zeroes the other lanes' ranges: the stored bounds are then a superset — more is staged, nothing is missed)
+        const uint32_t* bb = P.block_bounds + 8u * blk;
+        blo[0] = bb[0]; blo[1] = bb[1]; blo[2] = bb[2]; bhi[0] = bb[3]; bhi[1] = bb[4]; bhi[2] = bb[5];
+        staged = bhi[0] - blo[0] <= NBF_TILE && bhi[1] - blo[1] <= NBF_TILE && bhi[2] - blo[2] <= NBF_TILE;
+    } else {
+        staged = block_tile_bounds(R, s_red, blo, bhi, NBF_TILE);
+    }
     bool defer = !staged;                            // lean path only; wave-uniform from here on
     if (staged) {
 #pragma unroll
