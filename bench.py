@@ -344,7 +344,7 @@ def main():
         roofline["valu_issue"] = {"frac": crow.get("valu_issue_frac"), "insts_per_wave": crow.get("valu_insts_per_wave"),
                                   "waves_per_simd": crow.get("waves_per_simd"), "lds_busy_frac": crow.get("lds_busy_frac"),
                                   "wait_frac": crow.get("wait_frac"), "kernel": crow.get("kernel"),
-                                  "source": counters.get("source")}
+                                  "source": crow.get("source") or counters.get("source")}
     out = {
         "metric": "M particle-steps/s", "value": round(value, 2), "unit": "M particle-steps/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),

@@ -405,16 +405,6 @@ __device__ __forceinline__ void force_accum_tol(const StepParams& P, const TolCo
     A.fvy = __builtin_fmaf(nv.y - mv.y, kvv, A.fvy);
 }
 
-// The exact body behind a real call (FS_SLOW_NOINLINE): the hot loops then carry only the call's argument set-up
-// instead of the whole true-division body in their register allocation.
-#ifdef FS_SLOW_NOINLINE
-__device__ __attribute__((noinline)) void force_terms_exact_call(const StepParams* P, float2 me, float2 mv, float pressure,
-                                                                  float2 q, float2 nv, float nrho, uint32_t* seed,
-                                                                  ForceTerms* out) {
-    *out = force_terms<false>(*P, me, mv, pressure, q, nv, nrho, *seed);
-}
-#endif
-
 // The same terms with ONE true division per denominator (1/dst, 1/nrho) and div_by_rcp() for the
 // seven quotients — bit-identical to force_terms<false> whenever `good` comes back all-ones (operands
 // inside the proven range, fs_device.h).  Straight-line: no PRNG path, no tiny-distance path;
@@ -569,11 +559,7 @@ __device__ __forceinline__ void force_sweep_chunks(const StepParams& P, const Ro
                         wave_mask good = 0;
                         if (P.share_div) { T0 = force_terms_shared(P, me, mv, pressure, q0, v0, d0, good); good &= me_okm; }
                         if (good != wm(true)) {
-#ifdef FS_SLOW_NOINLINE
-                            force_terms_exact_call(&P, me, mv, pressure, q0, v0, d0.x, &A.seed, &T0);
-#else
                             T0 = force_terms<false>(P, me, mv, pressure, q0, v0, d0.x, A.seed);
-#endif
                         }
                     }
                     A.fpx += T0.px; A.fpy += T0.py; A.fvx += T0.vx; A.fvy += T0.vy;
@@ -630,37 +616,12 @@ __device__ __forceinline__ bool force_sweep_masks(const StepParams& P, const Row
     // The three masks are walked as a shift register (round 3): `cur` is the mask being consumed with its LDS / global
     // bases, (n1, n2) wait behind it.  Empty masks are squeezed out first, so "cur == 0 -> pull n1" is all a refill ever
     // needs, and the per-neighbour bit extraction touches ONE mask and ONE pair of bases instead of selecting among three
-    // masks and six bases.  Row order 0, 1, 2 (= the reference visiting order) is kept.  FS_WALK_SELECT: the round-2 form.
+    // masks and six bases.  Row order 0, 1, 2 (= the reference visiting order) is kept.
     // Software-pipelined: the LDS read and the two gathers of a later neighbour are issued before the terms of
     // neighbour k are evaluated, so a lane's own arithmetic covers their latency.  FS_PIPE_DEPTH = 1: neighbour
     // k+1 (one slot, rotated by moves); 2: neighbours k+1 and k+2 (three slots A, B, C refilled in turn, the loop
     // unrolled by three so no value is moved).
     const wave_mask me_okm = wm(me_ok);      // the lane's own "safe operand" classification (all lanes active here)
-#ifdef FS_WALK_SELECT
-    // plain registers: left as arrays the compiler turns the selects below into an indexed scratch load
-    uint32_t la0 = la[0] << 3, la1 = la[1] << 3, la2 = la[2] << 3, lo0 = R.lo[0], lo1 = R.lo[1], lo2 = R.lo[2];
-    asm volatile("" : "+v"(la0), "+v"(la1), "+v"(la2), "+v"(lo0), "+v"(lo1), "+v"(lo2));
-    uint32_t m0 = m[0], m1 = m[1], m2 = m[2];
-#define FS_FETCH(have, qn, vn, dn)                                                                                   \
-    do {                                                                                                             \
-        have = (m0 | m1 | m2) != 0u;                                                                                 \
-        if (have) {                                                                                                  \
-            const bool s0 = m0 != 0u, s1 = m1 != 0u;                                                                 \
-            const uint32_t cur = s0 ? m0 : s1 ? m1 : m2;                                                             \
-            const uint32_t t = (uint32_t)__builtin_clz(cur);                                                         \
-            const uint32_t bit = 0x80000000u >> t;                                                                   \
-            m0 ^= s0 ? bit : 0u;                                                                                     \
-            m1 ^= (!s0 && s1) ? bit : 0u;                                                                            \
-            m2 ^= (!s0 && !s1) ? bit : 0u;                                                                           \
-            qn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(s_flat) +                            \
-                                                  ((s0 ? la0 : s1 ? la1 : la2) + (t << 3))); /* la* in bytes */      \
-            /* both arrays hold 8-B elements: one 32-bit byte offset from the two SGPR bases (n <= 2^28) */          \
-            const uint32_t off = ((s0 ? lo0 : s1 ? lo1 : lo2) + t) << 3;                                             \
-            vn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vel_s) + off);                       \
-            dn = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rho2) + off); /* {rho, 1/rho} */     \
-        }                                                                                                            \
-    } while (0)
-#else
     uint32_t cur = m[0], n1 = m[1], n2 = m[2];
     uint32_t lac = la[0] << 3, la_1 = la[1] << 3, la_2 = la[2] << 3, loc = R.lo[0] << 3, lo_1 = R.lo[1] << 3, lo_2 = R.lo[2] << 3;   // bytes
     if (n1 == 0u) { n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0u; }
@@ -679,7 +640,6 @@ __device__ __forceinline__ bool force_sweep_masks(const StepParams& P, const Row
             if (cur == 0u) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0u; }         \
         }                                                                                                            \
     } while (0)
-#endif
 #define FS_PAIR(cur_valid, q0, v0, d0)                                                                               \
     do {                                                                                                             \
         if (cur_valid && MODE == 2) {                                                                                \

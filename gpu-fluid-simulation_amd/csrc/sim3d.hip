@@ -162,11 +162,7 @@ __device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
 #ifndef TILE3
 #define TILE3 400            // staged candidates per sweep row; one z-plane (3 rows) is staged at a time.  8 M, steps 10-110, strict / tolerance step: 352: 3.30 / 2.70, 384: 3.21 / 2.60, 400: 3.18 / 2.56, 408: 3.18 / 2.56 ms (408 is the most four workgroups per CU have room for)
 #endif
-#ifdef FS3_ROW_PAD           // round-2 layout (A/B): every row with its own 64 entries of scan slack
-#define TILE3_ROW (TILE3 + 64)
-#else
 #define TILE3_ROW TILE3      // rows 0 and 1 over-read into the next row's stage (masked off), only the last row needs the slack
-#endif
 #else
 #define TILE3 96             // a wave's row at rest: 10 cells x 8 particles; longer rows take the unstaged chunked sweep
 #define TILE3_ROW TILE3      // rows 0 and 1 over-read into the next row's stage, only the last row needs the slack below
@@ -181,7 +177,7 @@ __device__ __forceinline__ float dens3(const Params3& P, float4 me, float4 q) {
 #define FS3_STAGE_VEL 1
 #endif
 #ifndef FS3_CHUNK_BATCH
-#define FS3_CHUNK_BATCH 4    // 32-candidate chunks scanned per walk in the chunked sweep (1: the round-2 form)
+#define FS3_CHUNK_BATCH 4    // 32-candidate chunks scanned per walk in the chunked sweep (2 .. 4)
 #endif
 #define TILE3_VEL_OFF (TILE3_LDS * 16u)          // bytes from a staged position to the same candidate's velocity
 #define TILE3_FORCE_LDS (TILE3_LDS + (FS3_STAGE_VEL ? 3 * TILE3_ROW : 0))
@@ -202,10 +198,6 @@ __device__ __forceinline__ void shift_in_not_greater64(uint32_t& lo, uint32_t& h
     asm("v_cmp_nlt_f32 vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
         : "+v"(lo), "+v"(hi) : "v"(r2), "s"(lim) : "vcc");
 }
-// FS3_B96 (A/B): the scan reads 12-byte views of the staged records — ds_read_b96, 768 instead of 1 024 bytes per wave
-// instruction (only x, y, z are needed for r2); profiles/r03_rejected.md has the measurement.
-struct alignas(4) F3 { float x, y, z; };
-template <bool XYZ_ONLY = false>
 __device__ __forceinline__ void scan3_plane(const Params3& P, const RowRanges& R, const uint32_t* blo, float4 me,
                                             const float4* s_flat, u64m m[3], uint32_t la[3]) {
     const float lim = P.h2;
@@ -247,19 +239,6 @@ __device__ __forceinline__ void scan3_plane(const Params3& P, const RowRanges& R
         continue;
 #endif
         for (; __any(t < len); t += 4u) {                                 // t is wave-uniform
-#ifdef FS3_B96
-            if (XYZ_ONLY) {
-                const F3 q0 = *reinterpret_cast<const F3*>(base + t), q1 = *reinterpret_cast<const F3*>(base + t + 1u);
-                const F3 q2 = *reinterpret_cast<const F3*>(base + t + 2u), q3 = *reinterpret_cast<const F3*>(base + t + 3u);
-                const F3 qq[4] = {q0, q1, q2, q3};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
-                    shift_in_not_greater64(mlo, mhi, ox * ox + oy * oy + oz * oz, lim);
-                }
-                continue;
-            }
-#endif
             const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
             const float4 qq[4] = {q0, q1, q2, q3};
 #pragma unroll
@@ -405,7 +384,7 @@ __global__ __launch_bounds__(B3F) FS3_DENSITY_ATTR void k3_density(Params3 P, fl
             } else if (pclass == 1) {
                 u64m m[3];
                 uint32_t la[3];
-                scan3_plane<true>(P, R, blo, me, s_pred, m, la);
+                scan3_plane(P, R, blo, me, s_pred, m, la);
                 if (P.handoff && live) {
 #pragma unroll
                     for (int r = 0; r < 3; ++r) masks[(size_t)(plane * 3 + r) * P.n + i] = m[r];
@@ -630,14 +609,9 @@ __device__ __forceinline__ void walk3(const Params3& P, const Tol3& C, const u64
     if (n1 == 0ull) { n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }
     if (cur == 0ull) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }
     // Software-pipelined (as in the 2D kernel): the LDS read and the velocity gather of later neighbours are issued
-    // before the terms of neighbour k are evaluated.  FS3_PIPE_DEPTH 1: neighbour k+1 in flight (one slot); 2: k+1 and
-    // k+2 (three slots refilled in turn, the loop unrolled by three so no value is moved).  With the masks handed over
-    // the kernel is latency-bound (profiles/r03_counters_3d*.md: waves parked 65 % / 79 % of their lifetime in strict /
-    // tolerance mode) — but the second neighbour in flight costs 16 more registers, and with 72 - 80 already in use
-    // (and 180 - 200 bytes of scratch in the chunked paths) that loses more than it covers.
-#ifndef FS3_PIPE_DEPTH
-#define FS3_PIPE_DEPTH (FS3_STAGE_VEL ? 2 : 1)      // without the velocity stage (7 waves, 72 registers) depth 2 measured slower at every register budget (profiles/r03_rejected.md): 8 M, strict 1.95 -> 2.05 .. 2.37 ms
-#endif
+    // before the terms of neighbour k are evaluated — two neighbours ahead (k+1 and k+2: three slots refilled in turn, the
+    // loop unrolled by three so no value is moved).  With the velocity stage the kernel runs at 4 waves per SIMD and has the
+    // registers for it; the one-deep form it replaced, and the measurements at 7 waves, are in profiles/r03_rejected.md.
 #define FS3_FETCH(have, qn, vn)                                                                                      \
     do {                                                                                                             \
         have = cur != 0ull;                                                                                          \
@@ -651,17 +625,6 @@ __device__ __forceinline__ void walk3(const Params3& P, const Tol3& C, const u64
             if (cur == 0ull) { cur = n1; lac = la_1; loc = lo_1; n1 = n2; la_1 = la_2; lo_1 = lo_2; n2 = 0ull; }     \
         }                                                                                                            \
     } while (0)
-#if FS3_PIPE_DEPTH == 1
-    float4 qn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = qn;
-    bool have = false;
-    FS3_FETCH(have, qn, vn);
-    while (__any(have)) {
-        const bool cur_valid = have;
-        const float4 q0 = qn, v0 = vn;
-        FS3_FETCH(have, qn, vn);
-        if (cur_valid) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A);
-    }
-#else
     float4 qA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vA = qA, qB = qA, vB = qA, qC = qA, vC = qA;
     bool hA = false, hB = false, hC = false;
     FS3_FETCH(hA, qA, vA);
@@ -678,7 +641,6 @@ __device__ __forceinline__ void walk3(const Params3& P, const Tol3& C, const u64
         { const bool cv = hC; const float4 q0 = qC, v0 = vC; if (cv) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A); }
         FS3_FETCH(hC, qC, vC);
     }
-#endif
 #undef FS3_FETCH
 }
 
@@ -761,7 +723,6 @@ __device__ __forceinline__ void sweep3_chunks(const Params3& P, const Tol3& C, c
         const uint32_t hi = r == 0 ? hi0 : r == 1 ? hi1 : hi2;
         const uint32_t b0 = r == 0 ? b00 : r == 1 ? b01 : b02;
         const uint32_t len = hi - lo;
-#if FS3_CHUNK_BATCH > 1
         // FS3_CHUNK_BATCH chunks of 32 candidates are scanned before the walk starts and their masks are walked as one shift
         // register (kernels_step.hip force_sweep_chunks: a lane then waits for the wave's slowest lane once per 128
         // candidates instead of once per 32); the chunks of a batch are consecutive in the row, a refill advances the bases
@@ -821,51 +782,6 @@ __device__ __forceinline__ void sweep3_chunks(const Params3& P, const Tol3& C, c
 #undef FS3_FETCH_NEXT1
 #undef FS3_CAND
         }
-#else
-#pragma unroll 1
-        for (uint32_t c0 = 0; __any(c0 < len); c0 += 32u) {              // c0 is wave-uniform
-            const uint32_t clen = c0 < len ? (len - c0 < 32u ? len - c0 : 32u) : 0u;
-            const uint32_t g = clen ? lo + c0 : 0u;                      // global index of the chunk's first candidate
-            const uint32_t boff = (STAGED ? (clen ? (uint32_t)r * TILE3_ROW + (g - b0) : 0u) : g) << 4;
-            const char* src = STAGED ? reinterpret_cast<const char*>(s_flat) : reinterpret_cast<const char*>(pred);
-#define FS3_CAND(k) (*reinterpret_cast<const float4*>(src + (boff + ((k) << 4))))
-            uint32_t mask = 0, t = 0;
-            for (; __any(t < clen); t += 4u) {
-                const float4 q0 = FS3_CAND(t), q1 = FS3_CAND(t + 1u), q2 = FS3_CAND(t + 2u), q3 = FS3_CAND(t + 3u);
-                const float4 qq[4] = {q0, q1, q2, q3};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
-                    shift_in_not_greater32(mask, ox * ox + oy * oy + oz * oz, lim);
-                }
-            }
-            mask = t ? mask << (32u - t) : 0u;
-            mask &= clen ? 0xFFFFFFFFu << (32u - clen) : 0u;
-            if (r == 1 && self_plane && ii - g < clen) mask &= ~(0x80000000u >> (ii - g));   // k != i
-            float4 qn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = qn;
-            bool have = false;
-#define FS3_FETCH_NEXT1()                                                                                            \
-    do {                                                                                                             \
-        have = mask != 0u;                                                                                           \
-        if (have) {                                                                                                  \
-            const uint32_t tt = (uint32_t)__builtin_clz(mask);                                                       \
-            mask ^= 0x80000000u >> tt;                                                                               \
-            qn = FS3_CAND(tt);                                                                                       \
-            if (STAGED && FS3_STAGE_VEL) vn = *reinterpret_cast<const float4*>(src + (boff + (tt << 4)) + TILE3_VEL_OFF);  \
-            else vn = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(vel_s) + ((g + tt) << 4));      \
-        }                                                                                                            \
-    } while (0)
-            FS3_FETCH_NEXT1();
-            while (__any(have)) {
-                const bool cur_valid = have;
-                const float4 q0 = qn, v0 = vn;
-                FS3_FETCH_NEXT1();
-                if (cur_valid) pair3_accum<MODE>(P, C, me, mv, pressure, q0, v0, A);
-            }
-#undef FS3_FETCH_NEXT1
-#undef FS3_CAND
-        }
-#endif
     }
 }
 

@@ -133,3 +133,25 @@ def test_comm_failure_is_fs_err_comm(fs, tmp_path):
     assert out.returncode == 0, out.stderr
     assert out.stdout.startswith("5 "), out.stdout          # FS_ERR_COMM
     assert "librccl" in out.stdout
+
+
+def test_build_recipe_lists_every_included_header():
+    """a header the sources include but build.py does not list neither rebuilds the objects nor trips is_stale()
+    (bench.py --no-build would accept a stale library).  Every quoted #include under csrc/ must be a listed header."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("fs_build", os.path.join(ROOT, "gpu-fluid-simulation_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    listed = {os.path.normpath(os.path.join(b.CSRC, h)) for h in b.HEADERS}
+    seen = set()
+    for name in sorted(os.listdir(b.CSRC)):
+        if not name.endswith((".hip", ".h", ".hpp")):
+            continue
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(os.path.join(b.CSRC, name)).read(), flags=re.M):
+            seen.add(os.path.normpath(os.path.join(b.CSRC, inc)))
+    assert seen, "no quoted includes found: the scan is broken"
+    missing = sorted(p for p in seen if p not in listed)
+    assert not missing, f"included under csrc/ but not in build.py HEADERS: {missing}"
+    assert all(os.path.exists(p) for p in listed), "build.py lists a header that does not exist"
+    assert set(os.listdir(b.CSRC)) >= set(b.SOURCES), "build.py lists a source that does not exist"

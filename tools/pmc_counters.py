@@ -115,9 +115,14 @@ if latest:
         cur = json.load(open(latest))
     except (OSError, ValueError):
         cur = {"kernels": {}}
-    cur["source"] = (cur.get("source", "") + " || " if cur.get("kernels") and tag not in cur.get("source", "") else "") + src
+    # every kernel row names the run it came from (bench.py quotes roofline.valu_issue.source per kernel: a 2D kernel must never be
+    # attributed to a 3D run); the file-level "source" only lists the runs that contributed
+    runs = [r for r in cur.get("source", "").split(" || ") if r]
+    if src not in runs:
+        runs.append(src)
+    cur["source"] = " || ".join(runs)
     for k, d in rows.items():
-        cur["kernels"][k] = {c: d[c] for c in cols if c in d}
+        cur["kernels"][k] = dict({c: d[c] for c in cols if c in d}, source=src)
     json.dump(cur, open(latest, "w"), indent=1)
 for k in order[:12]:
     print(k, {c: rows[k].get(c) for c in ("us", "waves_per_simd", "valu_issue_frac", "valu_ginst_per_s_per_simd", "valu_insts_per_wave", "valu_cyc_per_inst", "lds_busy_frac", "wait_frac")})

@@ -8,6 +8,14 @@
 HBM bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024: on gfx950 FETCH_SIZE reports half of wide reads
 (MI355X_MICROARCH.md, HBM section); calibrated here on k_import_aos, which reads 32 B x N.
 """
+def _head():
+    import subprocess
+    try:
+        return subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, timeout=10).stdout.strip() or 'unknown (no git on this box: pass it as argv[6])'
+    except Exception:
+        return 'unknown (no git on this box: pass it as argv[6])'
+
+
 import collections, csv, glob, json, re, sys
 
 def per_kernel(d, counter):
@@ -49,7 +57,7 @@ latest = {
               "dam_break_2d_16M; HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE reports half of wide "
               "reads: MI355X_MICROARCH.md HBM section; check: k_import_aos reads 32 B x N). predict+key is fused into "
               "the sort's first kernel. Produced by tools/pmc_traffic.py from " + raw_out + ".",
-    "window": "rocprofv3 --pmc passes over bench.py --steps 10 --warmup 10 (both of its runs of the window, all 40 steps averaged), commit " + (sys.argv[6] if len(sys.argv) > 6 else "?"),
+    "window": "rocprofv3 --pmc passes over bench.py --steps 10 --warmup 10 (both of its runs of the window, all 40 steps averaged), commit " + (sys.argv[6] if len(sys.argv) > 6 else _head()),
     "bytes_per_step_by_pass": {"predict_key": 0, **{p: int(by_pass[p]) for p in ("sort", "reorder", "density", "force")}},
     "bytes_per_launch": per_launch,
     "particles": 1 << 24,
