@@ -130,8 +130,10 @@ sim.sync()
 t0 = time.perf_counter()
 for _ in range(a.steps):
     step()
+host = (time.perf_counter() - t0) / a.steps * 1e3      # what the host needs to ENQUEUE a step (the loop never waits for the GPU)
 sim.sync()
 el = (time.perf_counter() - t0) / a.steps * 1e3
+print(f"host enqueue time per step: {host:.4f} ms")
 sim.profile(True); sim.profile_read(True)
 for _ in range(a.steps):
     step()
