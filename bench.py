@@ -43,7 +43,7 @@ ALG_BYTES_3D = {"sort": 40 + 12, "reorder": 72 + 4, "density": 20, "force": 68} 
 ALG_TOTAL_3D = 216
 
 # which kernel carries a pass: EXACT names as rocprofv3 prints them (profiles/counters_latest.json keys), first match wins
-PASS_KERNEL = {"force": ["fsd::k_force<0, false>"], "density": ["fsd::k_density<false>"],
+PASS_KERNEL = {"force": ["fsd::k_force<0, false>"], "density": ["fsd::k_density<false, true>", "fsd::k_density<false, false>", "fsd::k_density<false>"],
                "sort": ["fsd::k_bitonic_local32<1, 4>", "fsd::k_bitonic_local32<1, 3>"], "reorder": ["fsd::k_reorder<true>"]}
 PASS_KERNEL_3D = {"force": ["fsd::k3_force<0>"], "density": ["fsd::k3_density<0>"],
                   "sort": ["fsd::k_bitonic_local32<2, 4>"], "reorder": ["fsd::k3_reorder"]}

@@ -8,6 +8,7 @@
 //                     (compute.wgsl:45-56) + dense cell-start table
 //   k_density       = calculate_density (compute.wgsl:59-74, funcs.wgsl:157-203)
 //   k_force         = move_particle + both force sweeps fused (compute.wgsl:79-299)
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -141,6 +142,9 @@ __device__ __forceinline__ float density_cube_tol(float h2, float2 me, float2 q,
     return __builtin_fmaf(t * t, t, acc);
 }
 
+// MASS1: the tick's particle_mass is exactly 1.0f (the reference's default, src/renderer.rs:374-388): `mass * kern` IS kern then
+// (x * 1.0f == x for every f32), and the multiplication — one of the ~14 instructions per candidate — is left out.
+template <bool MASS1 = false>
 __device__ __forceinline__ float density_term(const StepParams& P, float h2, float2 me, float2 q) {
     const float dx = q.x - me.x, dy = q.y - me.y;
     const float r2 = dx * dx + dy * dy;
@@ -149,12 +153,12 @@ __device__ __forceinline__ float density_term(const StepParams& P, float h2, flo
         const float diff = h2 - r2;
         kern = P.poly6_norm * diff * diff * diff;       // funcs.wgsl:77
     }
-    return P.mass * kern * 1.0f;                        // funcs.wgsl:192
+    return MASS1 ? kern : P.mass * kern * 1.0f;         // funcs.wgsl:192
 }
 
 // TOL (fs_options.math_mode = FS_MATH_TOLERANCE): r2 by one fma, max(h2 - r2, 0) instead of the compare/select, the
 // constant factor mass * 4/(pi h^8) applied once to the sum; stores {pressure_i, 1/rho_i} for the merged force terms.
-template <bool TOL>
+template <bool TOL, bool MASS1>
 __device__ __forceinline__ void density_block(const StepParams& P, uint32_t blk, uint32_t n, const float2* __restrict__ pred,
                                               const uint32_t* __restrict__ cs, const uint32_t* __restrict__ start_ref,
                                               const u64* __restrict__ pairs, const unsigned long long* __restrict__ safe,
@@ -216,20 +220,20 @@ __device__ __forceinline__ void density_block(const StepParams& P, uint32_t blk,
                 continue;
             }
             for (; k + 4u <= hi; k += 4u) {
-                const float t0 = density_term(P, h2, me, sp[k]);
-                const float t1 = density_term(P, h2, me, sp[k + 1u]);
-                const float t2 = density_term(P, h2, me, sp[k + 2u]);
-                const float t3 = density_term(P, h2, me, sp[k + 3u]);
+                const float t0 = density_term<MASS1>(P, h2, me, sp[k]);
+                const float t1 = density_term<MASS1>(P, h2, me, sp[k + 1u]);
+                const float t2 = density_term<MASS1>(P, h2, me, sp[k + 2u]);
+                const float t3 = density_term<MASS1>(P, h2, me, sp[k + 3u]);
                 rho += t0; rho += t1; rho += t2; rho += t3;
             }
-            for (; k < hi; ++k) rho += density_term(P, h2, me, sp[k]);
+            for (; k < hi; ++k) rho += density_term<MASS1>(P, h2, me, sp[k]);
         }
     } else {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
             for (uint32_t k = R.lo[r]; k < R.hi[r]; ++k) {
                 if (TOL) rho = density_cube_tol(h2, me, pred[k], rho);
-                else rho += density_term(P, h2, me, pred[k]);
+                else rho += density_term<MASS1>(P, h2, me, pred[k]);
             }
     }
     if (!live) return;
@@ -258,26 +262,26 @@ __device__ __forceinline__ void density_block(const StepParams& P, uint32_t blk,
         const u64* __restrict__ pairs, const unsigned long long* __restrict__ safe, float* __restrict__ rho_out,         \
         float2* __restrict__ rho2_out, uint32_t* __restrict__ force_defer, uint32_t* __restrict__ force_work,            \
         uint32_t* __restrict__ force_count
-template <bool TOL>
+template <bool TOL, bool MASS1>
 __global__ __launch_bounds__(FS_BLOCK) void k_density(FS_DENSITY_ARGS) {
     __shared__ float2 s_pred[3][NB_TILE];
     __shared__ uint32_t s_red[24];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
     uint32_t blk;
     if (!xcd_block(P, (n + FS_BLOCK - 1) / FS_BLOCK, &blk)) return;   // uniform: no live particle in this block
-    density_block<TOL>(P, blk, n, pred, cs, start_ref, pairs, safe, rho_out, rho2_out, force_defer, force_work, force_count, s_pred, s_red);
+    density_block<TOL, MASS1>(P, blk, n, pred, cs, start_ref, pairs, safe, rho_out, rho2_out, force_defer, force_work, force_count, s_pred, s_red);
 }
 // Edge-first slab step, column-major ids (fs_device.h EdgeBlocks): the density of the columns the edge columns' force launch
 // reads — the edge columns and one more towards the interior — ahead of the full launch, on the exchange stream.  (The full
 // launch writes the same values again.)
-template <bool TOL>
+template <bool TOL, bool MASS1>
 __global__ __launch_bounds__(FS_BLOCK) void k_density_edge(FS_DENSITY_ARGS) {
     __shared__ float2 s_pred[3][NB_TILE];
     __shared__ uint32_t s_red[24];
     const uint32_t n = *P.n_live;
     const EdgeBlocks E = edge_blocks(P, cs, n, 1u);
     for (uint32_t t = blockIdx.x; t < edge_block_count(E); t += gridDim.x) {
-        density_block<TOL>(P, edge_block_at(E, t), n, pred, cs, start_ref, pairs, safe, rho_out, rho2_out, force_defer, force_work,
+        density_block<TOL, MASS1>(P, edge_block_at(E, t), n, pred, cs, start_ref, pairs, safe, rho_out, rho2_out, force_defer, force_work,
                            force_count, s_pred, s_red);
         __syncthreads();                             // the LDS stage is reused
     }
@@ -1176,18 +1180,21 @@ void launch_reorder(hipStream_t st, const StepParams& P, const u64* pairs, const
 void launch_density(hipStream_t st, const StepParams& P, const float2* pred, const uint32_t* cs,
                     const uint32_t* start_ref, const u64* pairs, const unsigned long long* safe, float* rho, float2* rho2,
                     uint32_t* force_defer, uint32_t* force_work, uint32_t* force_count, uint32_t edge_grid) {
+    static const bool no_mass1 = getenv("FS_NO_MASS1") != nullptr;          // A/B: always the general form
+    const bool tol = P.fast_math == 2, mass1 = P.mass == 1.0f && !tol && !no_mass1;     // (the tolerance form applies the constant factor once anyway)
+#define FS_LAUNCH_DENSITY(K, G)                                                                                        \
+    do {                                                                                                               \
+        if (tol) hipLaunchKernelGGL((K<true, false>), dim3(G), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count); \
+        else if (mass1) hipLaunchKernelGGL((K<false, true>), dim3(G), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count); \
+        else hipLaunchKernelGGL((K<false, false>), dim3(G), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count); \
+    } while (0)
     if (edge_grid) {   // edge-first slab step: the edge columns' blocks only (k_density_edge)
-        if (P.fast_math == 2)
-            hipLaunchKernelGGL(k_density_edge<true>, dim3(edge_grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
-        else
-            hipLaunchKernelGGL(k_density_edge<false>, dim3(edge_grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
+        FS_LAUNCH_DENSITY(k_density_edge, edge_grid);
         return;
     }
     const uint32_t nb = nblk(P.n), grid = xcd_grid(nb, P.xcd_chunk_log2);
-    if (P.fast_math == 2)
-        hipLaunchKernelGGL(k_density<true>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
-    else
-        hipLaunchKernelGGL(k_density<false>, dim3(grid), dim3(FS_BLOCK), 0, st, P, pred, cs, start_ref, pairs, safe, rho, rho2, force_defer, force_work, force_count);
+    FS_LAUNCH_DENSITY(k_density, grid);
+#undef FS_LAUNCH_DENSITY
 }
 
 void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, const float2* vel_s, const float2* pred,

@@ -116,13 +116,15 @@ class SlabProtocolError(RuntimeError):
 class Transport:
     """Exchange one byte message with each slab neighbour (rank-1 = left, rank+1 = right)."""
 
-    def __init__(self, rank, world, message_bytes, device=None):
+    def __init__(self, rank, world, message_bytes, device=None, loopback=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.rank, self.world = rank, world
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world - 1 else None
+        if loopback:     # tests: both neighbours are this rank itself — what it sends right arrives as its right-hand incoming
+            self.left = self.right = rank          # message, likewise left (sends and receives to one peer match in order)
         self.device = device            # torch.device("cuda", i) for nccl, None for host (gloo)
         kw = {"dtype": torch.uint8, "device": device} if device is not None else {"dtype": torch.uint8}
         self.send_left = torch.zeros(message_bytes, **kw)
@@ -161,10 +163,12 @@ class NativeTransport:
     data path — what a Rust (or any non-Python) host calls.  torch.distributed is used ONCE, to ship rank 0's
     128-byte RCCL id to the other ranks; any rendezvous would do.  Opt-in: FS_NATIVE_RCCL=1 for bench.py --gpus N."""
 
-    def __init__(self, g, rank, world, message_bytes, device_index, dist=None):
+    def __init__(self, g, rank, world, message_bytes, device_index, dist=None, loopback=False):
         self.g, self.rank, self.world = g, rank, world
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world - 1 else None
+        if loopback:     # tests: fs_slab_exchange with left_rank == right_rank == own rank (recv_right <- send_right, recv_left <- send_left)
+            self.left = self.right = rank
         self.device = ("native", device_index)      # not None: the engine adapter writes the messages in place
         self.torch_device = None                    # where the (torch) re-balancing all-reduces run; set by the caller
         self.send_left, self.send_right, self.recv_left, self.recv_right = (
@@ -206,10 +210,10 @@ class HipSlabEngine:
     RCCL orders after the pack and before the unpack).  With a host transport (gloo) the
     messages are staged through fs_buffer device buffers."""
 
-    def __init__(self, g, settings, bounds, rank, world, capacity, recv_capacity, max_cols, device_index, transport):
+    def __init__(self, g, settings, bounds, rank, world, capacity, recv_capacity, max_cols, device_index, transport, **sim_kw):
         self.g = g
-        self.sim = g.SlabSimulation(settings, bounds[rank], bounds[rank + 1], rank > 0, rank < world - 1, capacity,
-                                    recv_capacity, max_cols, device=device_index)
+        self.sim = g.SlabSimulation(settings, bounds[rank], bounds[rank + 1], transport.left is not None, transport.right is not None,
+                                    capacity, recv_capacity, max_cols, device=device_index, **sim_kw)
         self.t = transport
         self.cuda = transport.device is not None
         if hasattr(transport, "bind"):

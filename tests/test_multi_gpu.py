@@ -619,3 +619,66 @@ def test_rebalance_inputs_equal_the_host_path_world2(fs, tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert [p.returncode for p in procs] == [0, 0], outs
     assert all("rebalance paths agree" in o for o in outs)
+
+
+TORCH_VS_NATIVE = r"""
+import os, sys, ctypes as C
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist          # torch FIRST: one HIP runtime per process
+import numpy as np
+import gpu_fluid_simulation_amd as g
+from gpu_fluid_simulation_amd import multi
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dev = torch.device("cuda", 0)
+n = 65536
+st, off, tick = g.dam_break_2d(n)
+hist, gw = multi.lattice_histogram(g, st, off)
+occ = np.nonzero(hist)[0]
+lo, hi = int(occ[0] + 0.3 * (occ[-1] - occ[0])), int(occ[0] + 0.55 * (occ[-1] - occ[0]))
+bounds = [lo, hi]
+lat = g.reference_lattice(st, off)
+rng = np.random.default_rng(4)
+lat["velocity"] = rng.uniform(-3, 3, size=lat["velocity"].shape).astype(np.float32)
+cols = multi.global_columns(lat["position"][:, 0], st.size.x, st.smoothing_radius)
+own = lat[(cols >= lo) & (cols < hi)]
+recv = 8192
+cap = own.shape[0] + 2 * recv + 4096
+mb = multi.HEADER_BYTES + multi.RECORD_BYTES * recv
+states = {}
+for kind in ("torch", "native"):
+    tr = (multi.Transport(0, 1, mb, device=dev, loopback=True) if kind == "torch"
+          else multi.NativeTransport(g, 0, 1, mb, 0, dist, loopback=True))
+    eng = multi.HipSlabEngine(g, st, bounds, 0, 1, cap, recv, gw, 0, tr)
+    assert eng.sim.step_mode == 1 and eng.sim.cfg.has_left and eng.sim.cfg.has_right
+    eng.sim.upload_owned(own)
+    drv = multi.SlabDriver(eng, tr, [lo, hi], gw, rebalance_every=0, check_counters=False)
+    ext = torch.cuda.ExternalStream(eng.sim.stream_ptr, device=dev)
+    with torch.cuda.stream(ext):
+        for _ in range(8):
+            drv.step(tick)          # no synchronisation in between: the exchange of step t + 1 runs beside step t's interior launch
+        eng.sync()
+        torch.cuda.synchronize()
+    rec, owned = eng.sim.download()
+    states[kind] = (rec.copy(), owned.copy(), eng.counters())
+    if kind == "native":
+        tr.close()
+a, b = states["torch"], states["native"]
+assert a[2] == b[2], (a[2], b[2])
+assert np.array_equal(a[1], b[1]) and np.array_equal(a[0][a[1]].view(np.uint8), b[0][b[1]].view(np.uint8)), "torch-nccl and fs_slab_exchange runs differ"
+assert a[1].sum() > 1000
+print("torch nccl exchange on the handle's exchange stream == fs_slab_exchange", a[2])
+dist.destroy_process_group()
+"""
+
+
+def test_torch_nccl_exchange_on_the_exchange_stream_equals_the_native_one(fs, tmp_path):
+    """bench.py --gpus N moves the messages with torch.distributed (nccl = RCCL) issued on the handle's exchange stream between
+    fs_slab_comm_begin / _end (multi.HipSlabEngine.exchange).  One GPU cannot host two nccl ranks, so the plumbing is exercised with
+    both neighbours being the rank itself (not a valid simulation: its own edge particles come back as migrants) and compared
+    with the same loop through fs_slab_exchange: eight free-running edge-first steps, byte-equal states and counters."""
+    script = tmp_path / "torch_vs_native.py"
+    script.write_text(TORCH_VS_NATIVE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29644")
+    out = subprocess.run([sys.executable, str(script), ROOT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "== fs_slab_exchange" in out.stdout
