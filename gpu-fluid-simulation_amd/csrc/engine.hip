@@ -693,6 +693,7 @@ void fs_destroy(fs_sim* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->comm) (void)hipStreamSynchronize(s->comm);        // an exchange / edge chain still in flight reads this handle's buffers
     s->release();
     delete s;
 }
