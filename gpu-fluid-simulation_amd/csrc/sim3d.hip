@@ -185,18 +185,14 @@ typedef unsigned long long u64m;
 
 // ---- pass masks of one staged z-plane -----------------------------------------------------------------------
 // A 3D row of three cells holds ~24 candidates at rest (8 particles per cell) and passes 32 as soon as the column
-// compresses, so the pass masks are 64 bits: v_cmp + two v_addc_co per candidate shift `!(r2 > h^2)` into a register
-// pair (see kernels_step.hip force_sweep_masks for the 2D, 32-bit form).  Candidate t of a row ends up at bit 63 - t.
+// compresses, so the pass masks are 64 bits, filled as two 32-bit shift registers: v_cmp + one v_addc_co per candidate shift
+// `!(r2 > h^2)` in (see kernels_step.hip force_sweep_masks for the 2D form).  Candidate t of a row ends up at bit 63 - t.
 // Valid for waves whose three rows hold <= 64 candidates each; the rows are read from the LDS stage `s_flat`
 // (TILE3_ROW entries per row).  Both the density and the force pass need exactly these masks: k3_density computes
 // them, walks them for its own sum and (Params3::handoff) stores them — 72 B per particle — so that k3_force does not
 // scan the 216 candidates a second time (~2 600 of its ~9 900 VALU instructions per wave).
 __device__ __forceinline__ void shift_in_not_greater32(uint32_t& mask, float r2, float lim) {
     asm("v_cmp_nlt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r2), "s"(lim) : "vcc");
-}
-__device__ __forceinline__ void shift_in_not_greater64(uint32_t& lo, uint32_t& hi, float r2, float lim) {
-    asm("v_cmp_nlt_f32 vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-        : "+v"(lo), "+v"(hi) : "v"(r2), "s"(lim) : "vcc");
 }
 __device__ __forceinline__ void scan3_plane(const Params3& P, const RowRanges& R, const uint32_t* blo, float4 me,
                                             const float4* s_flat, u64m m[3], uint32_t la[3]) {
@@ -207,7 +203,6 @@ __device__ __forceinline__ void scan3_plane(const Params3& P, const RowRanges& R
         la[r] = (uint32_t)r * TILE3_ROW + (len ? R.lo[r] - blo[r] : 0u);
         const float4* base = s_flat + la[r];
         uint32_t mlo = 0, mhi = 0, t = 0;
-#ifndef FS3_SCAN64
         // Two 32-bit shift registers, one v_addc_co per candidate (the 64-bit form needs two): candidates 0 .. 31 go
         // through `mhi`, the rest through `mlo`; t is wave-uniform, so the switch is a scalar branch.
         for (; t < 32u && __any(t < len); t += 4u) {
@@ -236,22 +231,6 @@ __device__ __forceinline__ void scan3_plane(const Params3& P, const RowRanges& R
             mask &= len ? ~0ull << (64u - len) : 0ull;
             m[r] = mask;
         }
-        continue;
-#endif
-        for (; __any(t < len); t += 4u) {                                 // t is wave-uniform
-            const float4 q0 = base[t], q1 = base[t + 1u], q2 = base[t + 2u], q3 = base[t + 3u];
-            const float4 qq[4] = {q0, q1, q2, q3};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float ox = qq[u].x - me.x, oy = qq[u].y - me.y, oz = qq[u].z - me.z;
-                shift_in_not_greater64(mlo, mhi, ox * ox + oy * oy + oz * oz, lim);
-            }
-        }
-        // candidate t sits at bit (trips - 1 - t): left-align, keep the lane's own len candidates
-        u64m mask = ((u64m)mhi << 32) | mlo;
-        mask = t ? mask << (64u - t) : 0ull;
-        mask &= len ? ~0ull << (64u - len) : 0ull;
-        m[r] = mask;
     }
 }
 // Is the mask form available for this wave's plane?  k3_density and k3_force must agree, so both call this with the
