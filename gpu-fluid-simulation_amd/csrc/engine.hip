@@ -471,7 +471,7 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     fsd::launch_force(st, P, pos_by_src ? s->pos.p : s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, pos_by_src ? s->pos_s.p : s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4,
                       s->aos_live ? (void*)s->aos.p : nullptr, s->side, s->ev_fork, s->ev_join,
-                      s->sortp.general_grid(), s->sortp.general_hint());
+                      s->sortp.general_grid(), s->sortp.general_hint(), 0u, prof ? nullptr : s->sortp.flight_event());
     if (pos_by_src) { float2* t = s->pos.p; s->pos.p = s->pos_s.p; s->pos_s.p = t; }   // the spare buffer now holds the state
     if (s->aos_live) s->aos_tick = s->tick;
     if (prof) {
@@ -479,7 +479,8 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
         FS_HIP(hipEventRecord(ev[6], st));             // FS_PASS_BOUNDARY: slab handles only
         s->prof_pending += 1;
     }
-    FS_HIP(s->sortp.step_enqueued(st));
+    if (prof) FS_HIP(s->sortp.step_enqueued(st));      // (the profile's own events are markers anyway)
+    else s->sortp.step_bound();                        // the general force launch carried the step's completion event
     FS_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -1188,7 +1189,9 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
         FS_TRY(hipStreamCreateWithPriority(&s->comm, hipStreamNonBlocking, hi_prio));
         FS_TRY(hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming));
         FS_TRY(hipEventCreateWithFlags(&s->ev_exch, hipEventDisableTiming));
-        FS_TRY(hipEventCreateWithFlags(&s->ev_fork2, hipEventDisableTiming));
+        // waited for by the exchange stream of this same device only: no system-scope fence (a write-back of every L2 behind the
+        // reorder kernel, which the simulation's own stream would sit out)
+        FS_TRY(hipEventCreateWithFlags(&s->ev_fork2, hipEventDisableTiming | hipEventDisableSystemFence));
         if (const char* e = getenv("FS_SLAB_BOUNDARY_COLS")) s->boundary_cols = (uint32_t)atoi(e) < 3u ? 3u : (uint32_t)atoi(e);
     }
     if (s->overlap) {

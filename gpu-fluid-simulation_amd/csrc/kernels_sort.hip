@@ -677,17 +677,23 @@ __global__ __launch_bounds__(256) void k_late_cert(const u64* __restrict__ pairs
                                                     uint32_t seq) {
     const uint32_t H = 1u << (s0 - 1u), nb = p2 >> s0;
     int ok = 1, ok1 = 1, ok2 = 1, ok3 = 1;
+    // Eleven keys per boundary, ALL loaded before any is compared (clamped index, sentinel selected afterwards): written with
+    // `p < n ? load : sentinel` operands inside && chains the loads were conditional on one another — eleven dependent round
+    // trips per boundary, 14.6 us for this one-workgroup kernel at 16 M particles (profiles/r03_window_5_25_kernels.txt).
     for (uint32_t b = 1u + threadIdx.x; b < nb; b += 256u) {
         const uint32_t m = b << s0;
-#define FS_KEY(p) ((p) < n ? (uint32_t)(pairs[(p)] >> 32) : 0xFFFFFFFFu)
-        const uint32_t left_max = FS_KEY(m - 1u), right_min = FS_KEY(m);
-        ok &= FS_KEY(m - H - 1u) <= right_min;
-        ok &= FS_KEY(m + H) >= left_max;
-        ok &= left_max <= FS_KEY(m + 2u * H);          // m + 2H == p2 reads as the sentinel
-        ok1 &= FS_KEY(m - (H >> 1) - 1u) <= right_min && FS_KEY(m + (H >> 1)) >= left_max;
-        ok2 &= FS_KEY(m - (H >> 2) - 1u) <= right_min && FS_KEY(m + (H >> 2)) >= left_max;
-        ok3 &= FS_KEY(m - (H >> 3) - 1u) <= right_min && FS_KEY(m + (H >> 3)) >= left_max;
-#undef FS_KEY
+        const uint32_t idx[11] = {m - 1u, m, m - H - 1u, m + H, m + 2u * H, m - (H >> 1) - 1u, m + (H >> 1),
+                                  m - (H >> 2) - 1u, m + (H >> 2), m - (H >> 3) - 1u, m + (H >> 3)};
+        uint32_t k[11];
+#pragma unroll
+        for (int j = 0; j < 11; ++j) k[j] = (uint32_t)(pairs[idx[j] < n ? idx[j] : n - 1u] >> 32);
+#pragma unroll
+        for (int j = 0; j < 11; ++j) k[j] = idx[j] < n ? k[j] : 0xFFFFFFFFu;      // m + 2H == p2 reads as the sentinel
+        const uint32_t left_max = k[0], right_min = k[1];
+        ok &= (int)(k[2] <= right_min) & (int)(k[3] >= left_max) & (int)(left_max <= k[4]);
+        ok1 &= (int)(k[5] <= right_min) & (int)(k[6] >= left_max);
+        ok2 &= (int)(k[7] <= right_min) & (int)(k[8] >= left_max);
+        ok3 &= (int)(k[9] <= right_min) & (int)(k[10] >= left_max);
     }
     const int all = __syncthreads_and(ok);
     const int a1 = __syncthreads_and(ok1), a2 = __syncthreads_and(ok2), a3 = __syncthreads_and(ok3);

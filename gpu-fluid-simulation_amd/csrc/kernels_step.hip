@@ -8,6 +8,7 @@
 //                     (compute.wgsl:45-56) + dense cell-start table
 //   k_density       = calculate_density (compute.wgsl:59-74, funcs.wgsl:157-203)
 //   k_force         = move_particle + both force sweeps fused (compute.wgsl:79-299)
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -726,14 +727,11 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
                                             AosParticle* __restrict__ aos_out, const float* __restrict__ rho_arr,
                                             uint32_t* __restrict__ defer_bits, uint32_t* __restrict__ worklist,
                                             uint32_t* __restrict__ work_count, float2 (*s_pred)[NBF_ROW],
-                                            uint32_t* s_red, uint32_t lane_particle = 0xFFFFFFFFu) {
+                                            uint32_t* s_red) {
     const uint32_t tid = threadIdx.x;
-    // GENERAL with a lane assignment (k_force_general, general_lane_order): thread `tid` works on the block's particle
-    // `lane_particle` (>= 256: none) — the waves then hold particles of similar candidate counts; otherwise particle `tid`
-    const uint32_t mine = (GENERAL && lane_particle != 0xFFFFFFFFu) ? lane_particle : tid;
-    const uint32_t i = blk * FS_BLOCK + (mine < FS_BLOCK ? mine : 0u);
-    bool live = i < n && mine < FS_BLOCK;
-    if (GENERAL) live = live && ((wave_bits >> (mine >> 6)) & 1u);  // only the waves handed over to the general path
+    const uint32_t i = blk * FS_BLOCK + tid;
+    bool live = i < n;
+    if (GENERAL) live = live && ((wave_bits >> (tid >> 6)) & 1u);   // only the waves handed over to the general path
     // lean path: a wave k_density pre-registered is being finished by a general workgroup of this same launch
     const bool pre = !GENERAL && ((wave_bits >> (tid >> 6)) & 1u);
     if (pre) live = false;
@@ -936,51 +934,6 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_FOR
     }
 }
 
-// Lane assignment of the general kernel (round 4).  A deferred wave holds particles of very different candidate counts — a
-// dense cluster next to ordinary fluid — and every lane waits for the wave's longest rows (lane utilisation 0.74 in the
-// dense regime, profiles/r03_counters_2d_dense.md).  Which lane evaluates which particle changes no particle's result (each
-// walks its own candidates in the reference order), so the particles of the block's deferred waves are dealt to the threads
-// in DESCENDING order of their candidate count: heavy particles share waves with heavy ones, waves without work return.
-// Returns the particle (0 .. 255) of this thread, or 256 for none.  Needs the density pass's block bounds (StepParams::
-// block_bounds: the bounds reduction assumes lanes in sorted order); without them the identity.
-__device__ __forceinline__ uint32_t general_lane_order(const StepParams& P, uint32_t blk, uint32_t n, uint32_t wave_bits,
-                                                       const float2* __restrict__ pred, const uint32_t* __restrict__ cs,
-                                                       uint32_t* s_cnt /*[66]*/, uint32_t* s_perm /*[256]*/) {
-    const uint32_t tid = threadIdx.x, i = blk * FS_BLOCK + tid;
-    const bool act = i < n && ((wave_bits >> (tid >> 6)) & 1u);
-    uint32_t w = 0;
-    if (act) {
-        uint32_t cx, cy;
-        int32_t cg;
-        uv_local(P, pred[i], &cx, &cy, &cg);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            uint32_t lo = 0, hi = 0;
-            if (row_range(P, cs, cx, cy + (uint32_t)(r - 1), 0u, &lo, &hi)) w += hi - lo;
-        }
-    }
-    if (tid < 66u) s_cnt[tid] = 0u;
-    s_perm[tid] = FS_BLOCK;
-    __syncthreads();
-    // 64 buckets of 8 candidates (a lean-path particle has ~36; rows of hundreds land in the last buckets); bucket 64 - b so that
-    // the prefix runs from the heaviest bucket down
-    const uint32_t b = act ? 63u - (w >> 3 < 63u ? w >> 3 : 63u) : 64u;
-    uint32_t slot = 0;
-    if (act) slot = atomicAdd(&s_cnt[b], 1u);
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t k = 0; k < 64u; ++k) { const uint32_t c = s_cnt[k]; s_cnt[k] = run; run += c; }
-        s_cnt[65] = run;
-    }
-    __syncthreads();
-    if (act) s_perm[s_cnt[b] + slot] = tid;
-    __syncthreads();
-    const uint32_t mine = s_perm[tid];
-    __syncthreads();                                 // s_cnt / s_perm are reused by the next worklist entry
-    return mine;
-}
-
 // General kernel: a fixed grid walks one of the two worklists with the complete body.
 //   which = 0: the waves k_density pre-registered (long rows / unstaged tiles: dense clusters) — launched on the
 //              simulation's second stream so that it runs BESIDE the lean kernel: a general workgroup's latency (a wave
@@ -996,23 +949,29 @@ template <int MODE, bool AOS>
 __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_GENERAL_WAVES, FS_GENERAL_WAVES))) void k_force_general(FS_FORCE_ARGS, uint32_t which, uint32_t* __restrict__ hint) {
     __shared__ float2 s_pred[3][NBF_ROW];
     __shared__ uint32_t s_red[24];
-    __shared__ uint32_t s_cnt[66], s_perm[FS_BLOCK];
     const uint32_t n = P.n_live ? *P.n_live : P.n;
     // how much work the lists held: the host sizes the next steps' grid of this kernel from it (a few steps late,
     // through pinned memory; an idle launch costs what its workgroups cost to come and go)
     if (hint && blockIdx.x == 0 && threadIdx.x == 0) *hint = which == 2u ? work_count[0] + work_count[1] : work_count[which];
+    // Which entry a workgroup starts with.  A list shorter than the grid (a small scene, the first dense clusters) would
+    // otherwise be worked off by the FIRST workgroups of the grid, neighbours in dispatch order, while most of the chip runs the
+    // workgroups that find nothing: grids of 40 k workgroups (sort_policy.h) deal consecutive entries to the 8 XCDs and, inside
+    // an XCD, to workgroups five apart (1 M particles: force pass -1.5 us).  Longer lists keep the plain order (consecutive
+    // entries are neighbouring blocks: they share their candidates in one XCD's L2).
+    const uint32_t J = gridDim.x >> 3, j = blockIdx.x >> 3;
+    const bool spread_ok = (gridDim.x & 7u) == 0u && J % 5u == 0u;
+    const uint32_t e_spread = spread_ok ? (((j % 5u) * (J / 5u) + j / 5u) << 3) | (blockIdx.x & 7u) : blockIdx.x;
     // which = 0 / 1: one list; which = 2: the pre-registered list, then the late one (the usual single follow-up launch)
     for (uint32_t w = (which == 2u ? 0u : which); w <= (which == 2u ? 1u : which); ++w) {
         const uint32_t count = work_count[w];        // written earlier in the stream (k_density / the lean kernel)
         const uint32_t* list = worklist + (w ? P.n / FS_BLOCK + 8u : 0u);
-        for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        for (uint32_t e = count < gridDim.x ? e_spread : blockIdx.x; e < count; e += gridDim.x) {
             const uint32_t blk = list[e];
             if (!block_may_advance(P, pairs, blk, n)) continue;          // uniform
             const uint32_t bits = defer_bits[2u * blk + w];
-            const uint32_t lane_particle = P.block_bounds ? general_lane_order(P, blk, n, bits, pred, cs, s_cnt, s_perm) : 0xFFFFFFFFu;
             force_block<MODE, AOS, true>(P, blk, n, bits, pos_s, vel_s, pred, rho2, cs, start_ref, pairs,
                                          tex, pos_out, vel_out, aos_out, rho_arr, defer_bits, worklist, work_count, s_pred,
-                                         s_red, lane_particle);
+                                         s_red);
             __syncthreads();                         // the LDS stage is reused by the next entry
         }
     }
@@ -1201,10 +1160,11 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out, const float* rho_arr, uint32_t* defer_bits, uint32_t* worklist,
                   uint32_t* work_count, void* aos_out, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
-                  uint32_t general_grid, uint32_t* general_hint, uint32_t edge_grid) {
+                  uint32_t general_grid, uint32_t* general_hint, uint32_t edge_grid, hipEvent_t done) {
     const uint32_t nb = nblk(P.n), grid = xcd_grid(nb, P.xcd_chunk_log2);
+    hipEvent_t stop_ev = nullptr;      // set for the pass's last launch only
 #define FS_LAUNCH_FORCE(K, M, A, G, S, ...)                                                                         \
-    hipLaunchKernelGGL((K<M, A>), dim3(G), dim3(FS_BLOCK), 0, S, P, pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex, \
+    hipExtLaunchKernelGGL((K<M, A>), dim3(G), dim3(FS_BLOCK), 0, S, nullptr, stop_ev, 0, P, pos_s, vel_s, pred, rho2, cs, start_ref, pairs, tex, \
                        pos_out, vel_out, (AosParticle*)aos_out, rho_arr, defer_bits, worklist, work_count, __VA_ARGS__)
 #define FS_LAUNCH_FORCE_MODE(K, G, S, ...)                                                                          \
     do {                                                                                                            \
@@ -1213,7 +1173,7 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
         else { if (aos_out) FS_LAUNCH_FORCE(K, 0, true, G, S, __VA_ARGS__); else FS_LAUNCH_FORCE(K, 0, false, G, S, __VA_ARGS__); }      \
     } while (0)
 #ifndef FS_GENERAL_GRID
-#define FS_GENERAL_GRID 4096u   // 16M, steps 150-250: force 1.175 (1024) -> 1.126 (2048) -> 1.117 ms (4096); steps 10-110 unchanged
+#define FS_GENERAL_GRID 4080u   // 16M, steps 150-250: force 1.175 (1024) -> 1.126 (2048) -> 1.117 ms (4096); steps 10-110 unchanged
 #endif
     uint32_t gg = general_grid ? general_grid : FS_GENERAL_GRID;      // the host's choice (engine.hip), else the full grid
     if (gg > nb) gg = nb;
@@ -1227,8 +1187,10 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
     else FS_LAUNCH_FORCE_MODE(k_force, grid, st, 0u);
     if (side) {
         (void)hipStreamWaitEvent(st, ev_join, 0);
+        stop_ev = done;
         FS_LAUNCH_FORCE_MODE(k_force_general, (nb < 256u ? nb : 256u), st, 1u, (uint32_t*)nullptr);
     } else {
+        stop_ev = done;
         FS_LAUNCH_FORCE_MODE(k_force_general, gg, st, 2u, general_hint);      // both lists in one follow-up launch
     }
 #undef FS_LAUNCH_FORCE_MODE

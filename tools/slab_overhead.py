@@ -37,7 +37,11 @@ ap.add_argument("--no-exchange", action="store_true", help="with --neighbours: h
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--boundary", type=int, default=0)
+ap.add_argument("--lib", default=None, help="a variant build of the library inside the package directory")
 a = ap.parse_args()
+if a.lib:
+    from gpu_fluid_simulation_amd import _abi
+    _abi._lib = _abi.load_library(os.path.join("gpu-fluid-simulation_amd", a.lib))
 
 n, world = a.n, a.world
 st, off, tick = g.dam_break_2d(n)
