@@ -169,6 +169,8 @@ struct fs_sim {
     hipEvent_t ev_exch = nullptr;          // comm stream: both incoming messages have arrived
     hipEvent_t ev_fork2 = nullptr;         // edge-first: the density pass is done, the edge columns' chain may start on `comm`
     bool exch_pending = false;             // fs_slab_step must wait for ev_exch
+    bool join_pending = false;             // edge-first: the simulation's stream has not yet waited for the edge columns' chain of the last step (slab_join)
+    bool edge_classified = false;          // edge-first: that chain also classified its particles' slots for the next pack
     uint32_t boundary_cols = 4;            // owned columns per neighboured edge left to the strips (>= 3)
     uint32_t pending_shift = 0;            // columns a window edge moved since the last pack: that step's migrants land deeper
     uint32_t adv_lo = 0, adv_hi = 0;       // interior columns of the step being enqueued
@@ -529,7 +531,7 @@ fs_status slab_interior(fs_sim* s) {
     const fsd::StepParams P = overlap_params(*s, false);
     hipEvent_t* ev = s->slab_prof ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
     if (ev) FS_HIP(hipEventRecord(ev[1], st));
-    fsd::launch_counting_sort_pairs(st, s->capacity, P.ncell, s->ncell, s->cs.p, s->csort.p, s->slab_counters.p, s->tick);
+    fsd::launch_counting_sort_pairs(st, s->capacity, P.ncell, s->ncell, s->cs.p, s->csort.p, s->slab_counters.p, s->tick, nullptr, s->safe.p);
     if (ev) FS_HIP(hipEventRecord(ev[2], st));
     fsd::launch_counting_reorder_slab(st, P, s->capacity, s->ncell, s->csort.p, s->pairs.p, s->cs.p, s->pos.p, s->vel.p, s->pos_s.p,
                                       s->vel_s.p, s->pred.p, s->key.p, s->owned.p, s->start_ref.p, s->safe.p, s->fdefer.p,
@@ -580,6 +582,18 @@ fs_status slab_boundary(fs_sim* s, const void* recv_left, const void* recv_right
 }
 
 }  // namespace
+
+// Edge-first slab step: the edge columns' chain of the last step (exchange stream) has advanced its particles and classified their
+// slots; the simulation's stream only waits for it when something other than the next pack -> exchange -> step cycle needs that
+// state (the cycle itself is ordered by the exchange's event).  Every entry point that reads or replaces the state calls this.
+static fs_status slab_join(fs_sim* s) {
+    if (s && s->slab && s->join_pending) {
+        FS_HIP(hipStreamWaitEvent(s->stream, s->ev_packed, 0));
+        s->join_pending = false;
+    }
+    return FS_OK;
+}
+#define FS_JOIN(s) do { fs_status jr_ = slab_join(s); if (jr_ != FS_OK) return jr_; } while (0)
 
 extern "C" {
 
@@ -718,7 +732,8 @@ static fs_status sort_health(fs_sim* s) {
 fs_status fs_sync(fs_sim* s) {
     if (!s) return fail(FS_ERR_INVALID, "null argument");
     FS_HIP(hipStreamSynchronize(s->stream));
-    if (s->comm && s->exch_pending) FS_HIP(hipStreamSynchronize(s->comm));   // an exchange issued but not yet consumed by fs_slab_step
+    // an exchange issued but not yet consumed by fs_slab_step / the edge columns' chain of the last edge-first step
+    if (s->comm && (s->exch_pending || s->join_pending)) { FS_HIP(hipStreamSynchronize(s->comm)); s->join_pending = false; }
     return sort_health(s);
 }
 
@@ -734,6 +749,7 @@ fs_status fs_grid_dims(const fs_sim* s, uint32_t* gw, uint32_t* gh) {
 
 fs_status fs_particles_device(fs_sim* s, const fs_particle** out) {
     if (!s || !out) return fail(FS_ERR_INVALID, "null argument");
+    FS_JOIN(s);
     FS_HIP(hipSetDevice(s->device));
     if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
     if (!(s->aos_live && s->aos_tick == s->tick && s->tick != 0)) {   // live view: the force pass already wrote it
@@ -748,6 +764,7 @@ fs_status fs_particles_device(fs_sim* s, const fs_particle** out) {
 
 fs_status fs_start_indices_device(fs_sim* s, const uint32_t** out, size_t* count) {
     if (!s || !out) return fail(FS_ERR_INVALID, "null argument");
+    FS_JOIN(s);
     *out = s->start_ref.p;
     if (count) *count = s->start_ref.n;
     return FS_OK;
@@ -761,6 +778,7 @@ fs_status fs_get_uniform(const fs_sim* s, fs_uniform* out) {
 
 fs_status fs_upload_force_field(fs_sim* s, const fs_vec2* field, uint32_t w, uint32_t h) {
     if (!s || !field) return fail(FS_ERR_INVALID, "null argument");
+    FS_JOIN(s);
     if (w != s->settings.texture_size.x || h != s->settings.texture_size.y)
         return fail(FS_ERR_INVALID, "force field dimensions differ from settings.texture_size");
     FS_HIP(hipSetDevice(s->device));
@@ -774,6 +792,7 @@ fs_status fs_upload_force_field(fs_sim* s, const fs_vec2* field, uint32_t w, uin
 
 fs_status fs_download_particles(fs_sim* s, fs_particle* dst, size_t n) {
     if (!s || (!dst && n)) return fail(FS_ERR_INVALID, "null argument");
+    FS_JOIN(s);
     if (n > s->n) n = s->n;
     const fs_particle* dev = nullptr;
     fs_status r = fs_particles_device(s, &dev);
@@ -785,6 +804,7 @@ fs_status fs_download_particles(fs_sim* s, fs_particle* dst, size_t n) {
 
 fs_status fs_upload_particles(fs_sim* s, const fs_particle* src, size_t n) {
     if (!s || (!src && n)) return fail(FS_ERR_INVALID, "null argument");
+    FS_JOIN(s);
     if (n > s->n) n = s->n;   // ResizableBuffer::write trims oversize data (src/buffer.rs:71-75)
     FS_HIP(hipSetDevice(s->device));
     if (!s->aos.p) FS_HIP(s->aos.alloc(s->capacity));
@@ -803,6 +823,7 @@ fs_status fs_upload_particles(fs_sim* s, const fs_particle* src, size_t n) {
 
 fs_status fs_download_start_indices(fs_sim* s, uint32_t* dst, size_t n) {
     if (!s || (!dst && n)) return fail(FS_ERR_INVALID, "null argument");
+    FS_JOIN(s);
     if (n > s->start_ref.n) n = s->start_ref.n;
     FS_HIP(hipSetDevice(s->device));
     if (n) FS_HIP(hipMemcpyAsync(dst, s->start_ref.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -812,6 +833,7 @@ fs_status fs_download_start_indices(fs_sim* s, uint32_t* dst, size_t n) {
 
 fs_status fs_upload_start_indices(fs_sim* s, const uint32_t* src, size_t n) {
     if (!s || (!src && n)) return fail(FS_ERR_INVALID, "null argument");
+    FS_JOIN(s);
     if (n > s->start_ref.n) n = s->start_ref.n;
     FS_HIP(hipSetDevice(s->device));
     if (n) FS_HIP(hipMemcpyAsync(s->start_ref.p, src, n * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
@@ -883,6 +905,7 @@ fs_status fs_generate_force_field(fs_sim* s, int device, const uint8_t* image, u
 fs_status fs_render_density(fs_sim* s, const fs_view* view, float* rgba_host) {
     if (!s || !view || !rgba_host) return fail(FS_ERR_INVALID, "null argument");
     if (s->slab) return fail(FS_ERR_UNSUPPORTED, "render on a slab handle");
+    FS_JOIN(s);
     if (view->width == 0 || view->height == 0 || (uint64_t)view->width * view->height > (1ull << 28))
         return fail(FS_ERR_INVALID, "bad image size");
     if (s->tick == 0) return fail(FS_ERR_INVALID, "render needs at least one fs_step (cell table not built yet)");
@@ -911,6 +934,7 @@ fs_status fs_profile_enable(fs_sim* s, int enable) {
 
 fs_status fs_profile_read(fs_sim* s, double ms[FS_PASS_COUNT], uint64_t* steps, int reset) {
     if (!s || !ms) return fail(FS_ERR_INVALID, "null argument");
+    FS_JOIN(s);
     fs_status r = drain_profile(s);
     if (r != FS_OK) return r;
     for (int k = 0; k < FS_PASS_COUNT; ++k) ms[k] = s->prof_ms[k];
@@ -1029,6 +1053,7 @@ fs_status fs_export_handle(fs_sim* s, int which, fs_mem_handle* out) {
     if (!s || !out) return fail(FS_ERR_INVALID, "null argument");
     if (s->slab) return fail(FS_ERR_UNSUPPORTED, "export on a slab handle");
     if (which != FS_EXPORT_PARTICLES && which != FS_EXPORT_START_INDICES) return fail(FS_ERR_INVALID, "unknown export");
+    FS_JOIN(s);
     FS_HIP(hipSetDevice(s->device));
     std::memset(out, 0, sizeof *out);
     void* base = nullptr;
@@ -1238,6 +1263,8 @@ fs_status fs_slab_create(const fs_settings* settings, int device, const fs_slab_
 fs_status fs_slab_upload_owned(fs_sim* s, const fs_particle* src, size_t n) {
     if (!s || !s->slab || (!src && n)) return fail(FS_ERR_INVALID, "bad argument");
     if (n > s->slab_main) return fail(FS_ERR_INVALID, "more owned particles than main slots");
+    FS_JOIN(s);
+    s->prepacked = false;                  // the state is replaced: messages built from the old one are void
     FS_HIP(hipSetDevice(s->device));
     if (n) FS_HIP(hipMemcpyAsync(s->aos.p, src, n * sizeof(fs_particle), hipMemcpyHostToDevice, s->stream));
     const fsd::StepParams P = make_params(*s);
@@ -1252,6 +1279,7 @@ fs_status fs_slab_upload_owned(fs_sim* s, const fs_particle* src, size_t n) {
 
 fs_status fs_slab_set_window(fs_sim* s, uint32_t own_lo, uint32_t own_hi) {
     if (!s || !s->slab) return fail(FS_ERR_INVALID, "not a slab handle");
+    FS_JOIN(s);
     if (own_lo >= own_hi || own_hi > s->grid_w || own_hi - own_lo < 4 || own_hi - own_lo > s->slab_cfg.max_cols)
         return fail(FS_ERR_INVALID, "bad owned window");
     if (s->slab_packed) return fail(FS_ERR_INVALID, "window change between pack and step");
@@ -1335,6 +1363,15 @@ fs_status fs_slab_pack(fs_sim* s, const fs_tick_settings* t, void* send_left, vo
                      s->pp_right == (s->slab_cfg.has_right ? send_right : nullptr) && s->pp_delta == t->delta &&
                      s->pp_lo == s->slab_cfg.own_lo && s->pp_hi == s->slab_cfg.own_hi;
     s->prepacked = false;
+    // pre: this launch needs nothing of the edge columns' chain (their slots are classified already: skip_edge) — no join; the
+    // chain is waited for through the exchange's event in fs_slab_step.  Otherwise: join, and take back the histogram counts
+    // that chain added with the parameters it expected (the scan has left the table zero everywhere else)
+    const bool skip_edge = pre && s->edge_classified;
+    if (!pre) {
+        FS_JOIN(s);
+        if (s->edge_classified && counting) FS_HIP(hipMemsetAsync(fsd::counting_sort_hist(s->csort.p), 0, (size_t)s->ncell * sizeof(uint32_t), s->stream));
+    }
+    s->edge_classified = false;
     s->pp_left = s->slab_cfg.has_left ? send_left : nullptr;
     s->pp_right = s->slab_cfg.has_right ? send_right : nullptr;
     s->last_tick = *t;
@@ -1343,7 +1380,7 @@ fs_status fs_slab_pack(fs_sim* s, const fs_tick_settings* t, void* send_left, vo
                           counting ? fsd::counting_sort_kt(s->csort.p, s->capacity, s->ncell) : s->pairs.p,
                           fsd::counting_sort_hist(s->csort.p), s->blockcnt.p, s->stage.p, s->msg_state.p, ++s->msg_epoch,
                           s->pp_left, s->pp_right, s->slab_counters.p, s->counter.p, s->safe.p, counting,
-                          s->overlap, !pre, s->key.p, s->adv_lo, s->adv_hi);
+                          s->overlap, !pre, s->key.p, s->adv_lo, s->adv_hi, skip_edge);
     FS_HIP(hipGetLastError());
     s->slab_packed = true;
     s->state_lo = s->slab_cfg.own_lo; s->state_hi = s->slab_cfg.own_hi;
@@ -1364,14 +1401,16 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     hipStream_t st = s->stream;
     hipEvent_t* ev = s->slab_prof ? &s->ev[(size_t)s->prof_pending * (FS_PASS_COUNT + 1)] : nullptr;
     const bool counting = s->opts.sort_mode == FS_SORT_COUNTING;
-    if (s->exch_pending) { FS_HIP(hipStreamWaitEvent(st, s->ev_exch, 0)); s->exch_pending = false; }
+    // the exchange was enqueued on the exchange stream behind the edge columns' chain: its event stands for the join as well
+    if (s->exch_pending) { FS_HIP(hipStreamWaitEvent(st, s->ev_exch, 0)); s->exch_pending = false; s->join_pending = false; }
+    else FS_JOIN(s);
     fsd::launch_slab_unpack(st, P, s->slab_main, s->slab_cfg.recv_capacity, s->slab_cfg.has_left ? recv_left : nullptr,
                             s->slab_cfg.has_right ? recv_right : nullptr, s->pos.p, s->vel.p,
                             counting ? fsd::counting_sort_kt(s->csort.p, s->capacity, s->ncell) : s->pairs.p,
                             fsd::counting_sort_hist(s->csort.p), s->slab_counters.p, counting);
     if (ev) FS_HIP(hipEventRecord(ev[1], st));
     if (counting) {
-        fsd::launch_counting_sort_pairs(st, s->capacity, P.ncell, s->ncell, s->cs.p, s->csort.p, s->slab_counters.p, s->tick);
+        fsd::launch_counting_sort_pairs(st, s->capacity, P.ncell, s->ncell, s->cs.p, s->csort.p, s->slab_counters.p, s->tick, nullptr, s->safe.p);
     } else {
         fsd::SortPlan per_stage;               // ghosts arrive at the end of the array every step: they travel far, no shifted merge
         per_stage.fuse_stage = 0;
@@ -1438,7 +1477,10 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
             PN.adv_lo = s->adv_lo; PN.adv_hi = s->adv_hi; PN.adv_outside = 1;
             fsd::launch_slab_prepack(es, PN, s->capacity, s->slab_cfg.recv_capacity, (int)s->slab_cfg.has_left, (int)s->slab_cfg.has_right,
                                      s->pos.p, s->vel.p, s->owned.p, s->key.p, s->blockcnt.p, s->stage.p, s->msg_state.p, ++s->msg_epoch,
-                                     s->pp_left, s->pp_right, s->slab_counters.p, s->cs.p, eg);
+                                     s->pp_left, s->pp_right, s->slab_counters.p, s->cs.p, eg, true, counting, s->slab_main,
+                                     counting ? fsd::counting_sort_kt(s->csort.p, s->capacity, s->ncell) : s->pairs.p,
+                                     fsd::counting_sort_hist(s->csort.p));
+            s->edge_classified = true;
             FS_HIP(hipEventRecord(s->ev_packed, es));       // the next step's messages are complete (and the edge columns advanced)
             s->prepacked = true;
             s->pp_delta = s->last_tick.delta; s->pp_lo = s->slab_cfg.own_lo; s->pp_hi = s->slab_cfg.own_hi;
@@ -1448,8 +1490,10 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
                               s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
                               s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint());
         if (ev) FS_HIP(hipEventRecord(ev[5], st));      // FS_PASS_FORCE: the interior launch
-        FS_HIP(hipStreamWaitEvent(st, s->ev_packed, 0));  // join: the next pack (and any download) sees the edge columns' new state
-        if (ev) { FS_HIP(hipEventRecord(ev[6], st)); s->prof_pending += 1; }     // FS_PASS_BOUNDARY: what the join still had to wait for
+        // no join here: the next fs_slab_pack leaves the edge columns' slots alone, and fs_slab_step waits for the exchange that
+        // follows their chain on the exchange stream; anything else that touches the state joins first (slab_join)
+        s->join_pending = true;
+        if (ev) { FS_HIP(hipEventRecord(ev[6], st)); s->prof_pending += 1; }     // FS_PASS_BOUNDARY: nothing left on this stream
     } else {
         fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                           s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
@@ -1463,6 +1507,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
 
 fs_status fs_slab_counters_read(fs_sim* s, fs_slab_counters* out) {
     if (!s || !s->slab || !out) return fail(FS_ERR_INVALID, "bad argument");
+    FS_JOIN(s);
     FS_HIP(hipSetDevice(s->device));
     uint32_t c[8];
     FS_HIP(hipMemcpyAsync(c, s->slab_counters.p, sizeof c, hipMemcpyDeviceToHost, s->stream));
@@ -1474,6 +1519,7 @@ fs_status fs_slab_counters_read(fs_sim* s, fs_slab_counters* out) {
 fs_status fs_slab_max_speed(fs_sim* s, float* out) {
     if (!s || !s->slab || !out) return fail(FS_ERR_INVALID, "bad argument");
     if (s->slab_packed) return fail(FS_ERR_INVALID, "fs_slab_max_speed between pack and step");
+    FS_JOIN(s);
     FS_HIP(hipSetDevice(s->device));
     uint32_t bits = 0;
     FS_HIP(hipMemsetAsync(s->slab_counters.p + 5, 0, sizeof(uint32_t), s->stream));
@@ -1492,6 +1538,7 @@ fs_status fs_slab_max_speed(fs_sim* s, float* out) {
 fs_status fs_slab_rebalance_stats(fs_sim* s, uint32_t* stats_dev, uint32_t* hist_dev, size_t grid_w_global) {
     if (!s || !s->slab || !stats_dev || !hist_dev || grid_w_global < s->grid_w) return fail(FS_ERR_INVALID, "bad argument");
     if (s->slab_packed) return fail(FS_ERR_INVALID, "fs_slab_rebalance_stats between pack and step");
+    FS_JOIN(s);
     FS_HIP(hipSetDevice(s->device));
     const fsd::StepParams P = make_params_of_state(*s);
     FS_HIP(hipMemsetAsync(hist_dev, 0, grid_w_global * sizeof(uint32_t), s->stream));
@@ -1507,6 +1554,7 @@ fs_status fs_slab_rebalance_stats(fs_sim* s, uint32_t* stats_dev, uint32_t* hist
 
 fs_status fs_slab_download(fs_sim* s, fs_particle* dst, uint8_t* owned, size_t cap, uint32_t* n_live) {
     if (!s || !s->slab || !dst || !owned || !n_live) return fail(FS_ERR_INVALID, "bad argument");
+    FS_JOIN(s);
     FS_HIP(hipSetDevice(s->device));
     const fsd::StepParams P = make_params_of_state(*s);
     uint32_t nl = 0;
@@ -1533,6 +1581,7 @@ fs_status fs_slab_download(fs_sim* s, fs_particle* dst, uint8_t* owned, size_t c
 
 fs_status fs_slab_column_histogram(fs_sim* s, uint32_t* hist, size_t grid_w_global) {
     if (!s || !s->slab || !hist || grid_w_global < s->grid_w) return fail(FS_ERR_INVALID, "bad argument");
+    FS_JOIN(s);
     FS_HIP(hipSetDevice(s->device));
     const fsd::StepParams P = make_params_of_state(*s);
     FS_HIP(hipMemsetAsync(s->hist.p, 0, s->hist.n * sizeof(uint32_t), s->stream));

@@ -66,13 +66,18 @@ void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, 
                       bool lists = true /* false: the messages were pre-built (launch_slab_prepack): only check that every particle
                                            the full classification flags was in the edge zone [own_lo, prev_adv_lo) u [prev_adv_hi, own_hi)
                                            of the last step (key_prev: its sorted keys) */,
-                      const uint32_t* key_prev = nullptr, uint32_t prev_adv_lo = 0, uint32_t prev_adv_hi = 0);
+                      const uint32_t* key_prev = nullptr, uint32_t prev_adv_lo = 0, uint32_t prev_adv_hi = 0,
+                      bool skip_edge = false /* with lists == false: the slots of the last step's edge-zone particles were classified by
+                                                launch_slab_prepack(classify) already — leave them alone */);
 // Edge-first step: the NEXT step's messages from the particles the StepParams::adv_outside force launch has just advanced.
 // `P_next`: window + tick constants of the next pack, adv_* as in that force launch; `epoch` unique among the handle's k_slab_msg launches.
 void launch_slab_prepack(hipStream_t st, const StepParams& P_next, uint32_t cap, uint32_t R, int has_left, int has_right,
                          const float2* pos, const float2* vel, const unsigned char* owned, const uint32_t* key_s, void* blockcnt,
                          uint32_t* stage, void* state, uint32_t epoch, void* msg_left, void* msg_right, uint32_t* counters,
-                         const uint32_t* cs, uint32_t edge_grid = 0 /* != 0 (column-major ids): walk only the edge columns' blocks */);
+                         const uint32_t* cs, uint32_t edge_grid = 0 /* != 0 (column-major ids): walk only the edge columns' blocks */,
+                         bool classify = false /* also do the next launch_slab_pack's work for the slots of the particles it takes:
+                                                  key, histogram ticket (`counting`) and out[] entry, the lost counter */,
+                         bool counting = false, uint32_t main_slots = 0, u64* out = nullptr, uint32_t* hist = nullptr);
 // Overlapped slab step — the boundary strips (kernels_slab.hip).  `P` = the main array's StepParams; win[4] = the two strip
 // windows as LOCAL column ranges [win[0], win[1]) and [win[2], win[3]); strip_counters: [0] live strip particles (written by the
 // strip's scan), [1] slots filled from the main array, [2] slots in use.
@@ -150,7 +155,8 @@ void launch_counting_reorder(hipStream_t st, const StepParams& P, uint32_t* scra
                              uint32_t* force_work_count);
 // n_dev (may be null): device word holding the number of slots in use (<= cap); the grids still cover `cap`
 void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, uint32_t ncell_alloc, uint32_t* cs, uint32_t* scratch,
-                                uint32_t* n_live_out, uint32_t epoch, const uint32_t* n_dev = nullptr);
+                                uint32_t* n_live_out, uint32_t epoch, const uint32_t* n_dev = nullptr,
+                                unsigned long long* safe_preset = nullptr /* the slots' "safe operand" words, set to all-ones for k_cs_fixreorder */);
 void launch_counting_reorder_slab(hipStream_t st, const StepParams& P, uint32_t cap, uint32_t ncell_alloc, uint32_t* scratch, u64* pairs,
                                   const uint32_t* cs, const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s,
                                   float2* pred_s, uint32_t* key_s, unsigned char* owned, uint32_t* start_ref,

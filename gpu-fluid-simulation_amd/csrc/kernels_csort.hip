@@ -131,9 +131,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_lookback(uint32_t* __restri
 // slot array whose length only the device knows); the grid still covers `n`.
 __global__ __launch_bounds__(CS_BLOCK) void k_cs_scatter(uint32_t n, uint32_t ncell, const u64* __restrict__ kt,
                                                          const uint32_t* __restrict__ cs, uint32_t* __restrict__ slot_src,
-                                                         const uint32_t* __restrict__ n_dev) {
+                                                         const uint32_t* __restrict__ n_dev,
+                                                         unsigned long long* __restrict__ safe_preset) {
     if (n_dev) { const uint32_t m = *n_dev; n = m < n ? m : n; }
     if (blockIdx.x * (CS_BLOCK * SC_ITEMS) >= n) return;
+    // slab handles: the "safe operand" words of this block's slots start as all-ones, k_cs_fixreorder (next in the stream) clears
+    // the unsafe particles' bits.  (Done here rather than in k_slab_pack: in an edge-first step the pack of tick t + 1 may run
+    // beside the edge columns' density launch of tick t, which still reads the words of tick t.)
+    if (safe_preset && threadIdx.x < CS_BLOCK * SC_ITEMS / 64u) safe_preset[blockIdx.x * (CS_BLOCK * SC_ITEMS / 64u) + threadIdx.x] = ~0ull;
     const uint32_t i0 = blockIdx.x * (CS_BLOCK * SC_ITEMS) + threadIdx.x;
     u64 e[SC_ITEMS];
 #pragma unroll
@@ -237,11 +242,11 @@ uint32_t* counting_sort_hist(uint32_t* scratch) { return scratch; }
 
 // Slab mode: kt / hist were filled by k_slab_pack + k_slab_unpack (kernels_slab.hip).
 void launch_counting_sort_pairs(hipStream_t st, uint32_t cap, uint32_t ncell, uint32_t ncell_alloc, uint32_t* cs, uint32_t* scratch,
-                                uint32_t* n_live_out, uint32_t epoch, const uint32_t* n_dev) {
+                                uint32_t* n_live_out, uint32_t epoch, const uint32_t* n_dev, unsigned long long* safe_preset) {
     const CsLayout L = cs_layout(scratch, cap, ncell_alloc);
     const uint32_t count = ncell + 1u, tiles = (count + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_scan_lookback, dim3(tiles), dim3(SCAN_BLOCK), 0, st, L.hist, count, cs, L.state, L.ticket, epoch, n_live_out);
-    hipLaunchKernelGGL(k_cs_scatter, dim3((cap + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), dim3(CS_BLOCK), 0, st, cap, ncell, L.kt, cs, L.slot_src, n_dev);
+    hipLaunchKernelGGL(k_cs_scatter, dim3((cap + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), dim3(CS_BLOCK), 0, st, cap, ncell, L.kt, cs, L.slot_src, n_dev, safe_preset);
 }
 uint32_t* counting_sort_slot_src(uint32_t* scratch, uint32_t n, uint32_t ncell_alloc) { return cs_layout(scratch, n, ncell_alloc).slot_src; }
 void launch_counting_reorder_slab(hipStream_t st, const StepParams& P, uint32_t cap, uint32_t ncell_alloc, uint32_t* scratch, u64* pairs,
@@ -270,7 +275,7 @@ void launch_counting_sort(hipStream_t st, const StepParams& P, const float2* pos
     hipLaunchKernelGGL(k_cs_hist, grid, block, 0, st, P, pos, vel, L.kt, L.hist, gap_counter, safe);
     hipLaunchKernelGGL(k_scan_lookback, dim3((count + SCAN_TILE - 1) / SCAN_TILE), dim3(SCAN_BLOCK), 0, st, L.hist, count, cs, L.state, L.ticket,
                        epoch, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_cs_scatter, dim3((n + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), block, 0, st, n, ncell, L.kt, cs, L.slot_src, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_cs_scatter, dim3((n + CS_BLOCK * SC_ITEMS - 1) / (CS_BLOCK * SC_ITEMS)), block, 0, st, n, ncell, L.kt, cs, L.slot_src, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
 }
 void launch_counting_reorder(hipStream_t st, const StepParams& P, uint32_t* scratch, u64* pairs, const uint32_t* cs,
                              const float2* pos_in, const float2* vel_in, float2* pos_s, float2* vel_s, float2* pred_s,

@@ -85,16 +85,26 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t c
                                                         uint32_t* __restrict__ counters, uint32_t* __restrict__ gap_counter,
                                                         unsigned long long* __restrict__ safe,
                                                         const uint32_t* __restrict__ key_prev, uint32_t prev_adv_lo,
-                                                        uint32_t prev_adv_hi) {
+                                                        uint32_t prev_adv_hi, int skip_edge) {
     const uint32_t i = blockIdx.x * SL_BLOCK + threadIdx.x;
     if (i == 0) *gap_counter = 0;          // cell-table worklist of this step (bitonic mode: k_slab_reorder)
-    if (COUNTING && i < (cap + 63u) / 64u) safe[i] = ~0ull;             // k_cs_fixreorder clears the unsafe bits
     const uint32_t n_prev = *P.n_live;
     unsigned char f = 0;
     uint32_t key = FS_DEAD_KEY;
     if (overlap && i == 0 && n_prev > main_slots) atomicAdd(&counters[3], 1u);   // the sorted prefix ran into the migrant slots
+    // lists == 0 (the messages were pre-built): where was this particle in the last step?  In the edge zone — then the edge
+    // columns' chain of that step advanced it, put it into the messages and, with skip_edge, classified its slot for this step's
+    // sort as well (k_slab_prepack: this launch then neither reads nor writes anything of it, and need not wait for that chain)
+    bool was_edge = false, skipped = false;
+    if (!lists && i < main_slots && i < n_prev && owned[i]) {
+        uint32_t cxl, cy;
+        key_to_local(P, key_prev[i], &cxl, &cy);
+        const int32_t cg = (int32_t)cxl + P.col_origin;
+        was_edge = cg >= (int32_t)P.own_lo && cg < (int32_t)P.own_hi && !(cg >= (int32_t)prev_adv_lo && cg < (int32_t)prev_adv_hi);
+        skipped = skip_edge && was_edge;
+    }
     if (i < main_slots || (overlap && i < cap)) {
-        if ((i < main_slots ? i < n_prev : true) && owned[i]) {
+        if ((i < main_slots ? i < n_prev : true) && owned[i] && !skipped) {
             const float2 pr = predict_pos(P, pos[i], vel[i]);
             uint32_t cxg;
             key = slab_key(P, pr, &cxg);
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t c
             if (!has_left && cxg < P.own_lo) atomicAdd(&counters[2], 1u);    // left the domain partition
             if (!has_right && cxg >= P.own_hi) atomicAdd(&counters[2], 1u);
         }
-        if (!COUNTING) out[i] = ((u64)key << 32) | (u64)i;
+        if (!COUNTING && !skipped) out[i] = ((u64)key << 32) | (u64)i;
     } else if (i < n_prev && i < cap && owned[i]) {
         // Slot capacity exceeded: the last step left more live records than main slots, and this owned
         // particle sits where the incoming messages will be unpacked.  It cannot be carried over —
@@ -118,20 +128,16 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_pack(StepParams P, uint32_t c
         uint32_t base = 0;
         if (r.is_head) base = atomicAdd(&hist[k], r.length);
         base = __shfl(base, r.head_lane);
-        if (i < main_slots || (overlap && i < cap)) out[i] = ((u64)key << 32) | (u64)(active ? base + r.offset : 0u);
+        if ((i < main_slots || (overlap && i < cap)) && !skipped) out[i] = ((u64)key << 32) | (u64)(active ? base + r.offset : 0u);
     }
     if (lists) {
         block_message_lists(f, i, blockIdx.x, blockcnt, stage_l, stage_r);
-    } else if (f) {
+    } else if (f && !was_edge) {
         // The messages of this step were built at the end of the last one, from the particles its edge-column force launch had
         // advanced by then (k_slab_prepack).  This full classification flags the same particles — unless one reached the 2-column
         // band from farther inside than the edge zone (its key of the last step says where it was): then the message that went
         // out lacks it.  Counted in far_halo (the edge zone was too narrow for its speed: fs_slab_set_boundary_cols).
-        uint32_t cxl, cy;
-        key_to_local(P, key_prev[i], &cxl, &cy);
-        const int32_t cg = (int32_t)cxl + P.col_origin;
-        const bool was_edge = cg >= (int32_t)P.own_lo && cg < (int32_t)P.own_hi && !(cg >= (int32_t)prev_adv_lo && cg < (int32_t)prev_adv_hi);
-        if (!was_edge) atomicAdd(&counters[4], 1u);
+        atomicAdd(&counters[4], 1u);
     }
 }
 
@@ -147,7 +153,9 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_prepack(StepParams P, int has
                                                            const unsigned char* __restrict__ owned,
                                                            const uint32_t* __restrict__ key_s, const uint32_t* __restrict__ cs,
                                                            uint2* __restrict__ blockcnt,
-                                                           uint32_t* __restrict__ stage_l, uint32_t* __restrict__ stage_r) {
+                                                           uint32_t* __restrict__ stage_l, uint32_t* __restrict__ stage_r,
+                                                           int classify, int counting, uint32_t main_slots, u64* __restrict__ out,
+                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ counters) {
     const uint32_t n = *P.n_live;
     // edge_walk (column-major ids): a small grid walks the blocks of the edge columns only (fs_device.h EdgeBlocks; k_slab_msg and
     // k_slab_gather take every other block's counts as zero); otherwise one workgroup per 256-slot block of the whole array
@@ -159,15 +167,35 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_prepack(StepParams P, int has
         const uint32_t blk = edge_walk ? edge_block_at(E, t) : t;
         const uint32_t i = blk * SL_BLOCK + threadIdx.x;
         unsigned char f = 0;
+        uint32_t key = FS_DEAD_KEY;
+        bool mine = false;                                  // classify: this launch does the next pack's work for the slot
         if (i < n && owned[i]) {
             uint32_t cxl, cy;
             key_to_local(P, key_s[i], &cxl, &cy);
             const int32_t cg = (int32_t)cxl + P.col_origin;
             if (slab_advances(P, cg)) {                     // advanced already: pos / vel hold its new state
                 uint32_t cxg;
-                (void)slab_key(P, predict_pos(P, pos[i], vel[i]), &cxg);
+                key = slab_key(P, predict_pos(P, pos[i], vel[i]), &cxg);
                 if (has_left && cxg < P.own_lo + 2u) f |= 1;
                 if (has_right && cxg + 2u >= P.own_hi) f |= 2;
+                mine = classify && i < main_slots;
+                if (mine) {                                 // exactly k_slab_pack's bookkeeping for an owned, carried-over slot
+                    if (!has_left && cxg < P.own_lo) atomicAdd(&counters[2], 1u);
+                    if (!has_right && cxg >= P.own_hi) atomicAdd(&counters[2], 1u);
+                }
+            }
+        }
+        if (classify) {
+            if (counting) {
+                const bool active = mine && key != FS_DEAD_KEY;
+                const uint32_t k = key < P.ncell ? key : P.ncell - 1u;
+                const WaveRun r = wave_run(k, active);
+                uint32_t base = 0;
+                if (r.is_head) base = atomicAdd(&hist[k], r.length);
+                base = __shfl(base, r.head_lane);
+                if (mine) out[i] = ((u64)key << 32) | (u64)(active ? base + r.offset : 0u);
+            } else if (mine) {
+                out[i] = ((u64)key << 32) | (u64)i;
             }
         }
         block_message_lists(f, i, blk, blockcnt, stage_l, stage_r);
@@ -674,7 +702,8 @@ void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, 
                       int has_right, const float2* pos, const float2* vel, const unsigned char* owned, u64* out,
                       uint32_t* hist, void* blockcnt, uint32_t* stage /* 2 x capacity words */, void* state, uint32_t epoch,
                       void* msg_left, void* msg_right, uint32_t* counters, uint32_t* gap_counter, unsigned long long* safe,
-                      bool counting, bool overlap, bool lists, const uint32_t* key_prev, uint32_t prev_adv_lo, uint32_t prev_adv_hi) {
+                      bool counting, bool overlap, bool lists, const uint32_t* key_prev, uint32_t prev_adv_lo, uint32_t prev_adv_hi,
+                      bool skip_edge) {
     // covers ALL slots (P.n = capacity): slots past `main_slots` only check for stranded owned particles
     const uint32_t cap = P.n > main_slots ? P.n : main_slots;
     const uint32_t blocks = nb(cap), groups = (blocks + MSG_GROUP - 1u) / MSG_GROUP;
@@ -684,10 +713,10 @@ void launch_slab_pack(hipStream_t st, const StepParams& P, uint32_t main_slots, 
     SlabHeader* hr = (SlabHeader*)msg_right;
     if (counting)
         hipLaunchKernelGGL(k_slab_pack<true>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, overlap ? 1 : 0, lists ? 1 : 0, has_left, has_right, pos,
-                           vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe, key_prev, prev_adv_lo, prev_adv_hi);
+                           vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe, key_prev, prev_adv_lo, prev_adv_hi, skip_edge ? 1 : 0);
     else
         hipLaunchKernelGGL(k_slab_pack<false>, dim3(blocks), dim3(SL_BLOCK), 0, st, P, cap, main_slots, 0, lists ? 1 : 0, has_left, has_right, pos,
-                           vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe, key_prev, prev_adv_lo, prev_adv_hi);
+                           vel, owned, out, hist, (uint2*)blockcnt, stage_l, stage_r, counters, gap_counter, safe, key_prev, prev_adv_lo, prev_adv_hi, skip_edge ? 1 : 0);
     if ((!hl && !hr) || !lists) return;                                 // no neighbour / messages pre-built: nothing to send
     launch_slab_msg(st, blocks, groups, R, blockcnt, stage_l, stage_r, pos, vel, state, epoch, hl, hr, counters, P);
 }
@@ -698,7 +727,8 @@ size_t slab_msg_groups(uint32_t cap) { return (nb(cap) + MSG_GROUP - 1u) / MSG_G
 void launch_slab_prepack(hipStream_t st, const StepParams& P_next, uint32_t cap, uint32_t R, int has_left, int has_right,
                          const float2* pos, const float2* vel, const unsigned char* owned, const uint32_t* key_s, void* blockcnt,
                          uint32_t* stage, void* state, uint32_t epoch, void* msg_left, void* msg_right, uint32_t* counters,
-                         const uint32_t* cs, uint32_t edge_grid) {
+                         const uint32_t* cs, uint32_t edge_grid, bool classify, bool counting, uint32_t main_slots, u64* out,
+                         uint32_t* hist) {
     const uint32_t blocks = nb(cap), groups = (blocks + MSG_GROUP - 1u) / MSG_GROUP;
     uint32_t* stage_l = stage;
     uint32_t* stage_r = stage + (size_t)blocks * SL_BLOCK;
@@ -707,7 +737,8 @@ void launch_slab_prepack(hipStream_t st, const StepParams& P_next, uint32_t cap,
     if (!hl && !hr) return;
     const bool walk = edge_grid != 0 && P_next.transposed;
     hipLaunchKernelGGL(k_slab_prepack, dim3(walk ? edge_grid : blocks), dim3(SL_BLOCK), 0, st, P_next, has_left, has_right, walk ? 1 : 0,
-                       pos, vel, owned, key_s, cs, (uint2*)blockcnt, stage_l, stage_r);
+                       pos, vel, owned, key_s, cs, (uint2*)blockcnt, stage_l, stage_r, classify ? 1 : 0, counting ? 1 : 0, main_slots, out,
+                       hist, counters);
     launch_slab_msg(st, blocks, groups, R, blockcnt, stage_l, stage_r, pos, vel, state, epoch, hl, hr, counters, P_next,
                     walk ? cs : nullptr, edge_grid);
 }
