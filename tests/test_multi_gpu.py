@@ -541,6 +541,56 @@ def test_edge_first_prebuilt_messages_equal_a_full_pack(fs):
         sim.close()
 
 
+def test_edge_first_state_replaced_or_window_moved_between_steps(fs):
+    """What an edge-first step leaves behind for the next one — pre-built messages, the edge columns' slots already classified
+    (their histogram counts included) — is void when the state is replaced (fs_slab_upload_owned) or the window moves
+    (fs_slab_set_window) in between: the next pack must then do the whole job, and end up byte for byte where the serial step does."""
+    sims, bufs = [], []
+    for serial in (False, True):
+        sim, st, tick, own, (lo, hi) = _one_slab(fs, 65536, 0.30, 0.55, recv=8192, serial=serial)
+        sims.append(sim)
+        bufs.append({k: fs.ResizableBuffer(k, np.uint8, sim.message_bytes) for k in ("sl", "sr", "e")})
+    P = lambda b: C.c_void_p(b.device_ptr)
+
+    def cycle(label):
+        msgs = []
+        for sim, b in zip(sims, bufs):
+            sim.pack(tick, P(b["sl"]), P(b["sr"]))
+            sim.wait_packed()
+            msgs.append((b["sl"].read(), b["sr"].read()))
+        for e, f in zip(msgs[0], msgs[1]):
+            cnt = int(f[:16].view(np.uint32)[0])
+            assert np.array_equal(e[:16 + 16 * cnt], f[:16 + 16 * cnt]), f"{label}: messages differ"
+        for sim, b in zip(sims, bufs):
+            sim.step(P(b["e"]), P(b["e"]))
+            sim.sync()
+        a, oa = sims[0].download(); c, oc = sims[1].download()
+        assert np.array_equal(oa, oc) and np.array_equal(a[oa].view(np.uint8), c[oc].view(np.uint8)), f"{label}: states differ"
+        return a[oa]
+
+    for k in range(3):
+        cycle(f"warm-up {k}")
+    # 1. the state is replaced: the same particles shifted by a third of a cell, velocities reversed
+    rep = own.copy()
+    rep["position"][:, 0] += np.float32(0.07)
+    rep["predicted_position"] = rep["position"]
+    rep["velocity"] *= np.float32(-1.0)
+    for sim in sims:
+        sim.upload_owned(rep)
+    for k in range(3):
+        cycle(f"after the upload {k}")
+    # 2. the window moves by one column on either side (what a re-balancing does)
+    for sim in sims:
+        sim.set_window(lo + 1, hi - 1)
+    for k in range(3):
+        last = cycle(f"after the window move {k}")
+    assert last.shape[0] > 0
+    for sim in sims:
+        c = sim.counters()
+        assert c["overflow"] == 0, c
+        sim.close()
+
+
 def test_edge_zone_narrower_than_the_travel_is_counted(fs):
     """A particle that reaches the 2-column halo band from farther inside than the edge zone is missing from the pre-built message;
     the next fs_slab_pack — which classifies every slot anyway — counts it in far_halo (multi.SlabDriver raises on it), and a zone
