@@ -667,20 +667,23 @@ static int sort_skip_stage() {
 // the launches of both plans are in the stream and each returns at once unless the verdict names its plan, so the
 // result is the network's in every case (uploads, fast flows: the conditions fail and the per-stage plan runs).
 #define SORT_NO_PLAN 255u
-// plan words (dirty[sort_plan_word(n) ..]): [0] verdict, [1] / [2] plan counters, [3] fallback barrier, [4] fallback
+// plan words (dirty[sort_plan_word(n) ..], 16 of them, zero at create; [8] failure bits / [9] ticket of k_late_cert's grid):
+// [0] verdict, [1] / [2] plan counters, [3] fallback barrier, [4] fallback
 // barrier time-outs, [5] fit class of the last certificate, [6] calls in which the stand-by kernel had work.
 // Fit class: the largest j <= 3 for which (C2), (C3) still hold with windows of H / 2^j — how much room the moves of
 // this step left; the host's choice of the next steps' stage reads it (engine.hip), never the result.
 // feedback (optional, host-visible): [1] stage, [2] verdict, [3] fit class, [4] time-outs, then [0] = seq.
+// Round 4: a grid of small workgroups instead of one of 256 threads.  The kernel's time was never its arithmetic: at 16 M
+// particles it reads 512 x 11 keys 256 KB apart — every one a TLB miss, all of them queued on ONE compute unit's address
+// translation (14.6 us, profiles/r03_window_5_25_kernels.txt).  Spread over the chip the misses are taken in parallel; the
+// workgroups OR their failure bits into plan[8], and the last one to arrive (ticket plan[9]) publishes the verdict.
 __global__ __launch_bounds__(256) void k_late_cert(const u64* __restrict__ pairs, uint32_t n, uint32_t p2, uint32_t s0,
                                                     uint32_t* __restrict__ plan, uint32_t* __restrict__ feedback,
                                                     uint32_t seq) {
     const uint32_t H = 1u << (s0 - 1u), nb = p2 >> s0;
-    int ok = 1, ok1 = 1, ok2 = 1, ok3 = 1;
-    // Eleven keys per boundary, ALL loaded before any is compared (clamped index, sentinel selected afterwards): written with
-    // `p < n ? load : sentinel` operands inside && chains the loads were conditional on one another — eleven dependent round
-    // trips per boundary, 14.6 us for this one-workgroup kernel at 16 M particles (profiles/r03_window_5_25_kernels.txt).
-    for (uint32_t b = 1u + threadIdx.x; b < nb; b += 256u) {
+    uint32_t bad = 0;                    // bit 0: (C2)-(C4) fail; bits 1..3: (C2), (C3) fail with windows of H/2, H/4, H/8
+    // Eleven keys per boundary, all loaded before any is compared (clamped index, sentinel selected afterwards).
+    for (uint32_t b = 1u + blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
         const uint32_t m = b << s0;
         const uint32_t idx[11] = {m - 1u, m, m - H - 1u, m + H, m + 2u * H, m - (H >> 1) - 1u, m + (H >> 1),
                                   m - (H >> 2) - 1u, m + (H >> 2), m - (H >> 3) - 1u, m + (H >> 3)};
@@ -690,24 +693,35 @@ __global__ __launch_bounds__(256) void k_late_cert(const u64* __restrict__ pairs
 #pragma unroll
         for (int j = 0; j < 11; ++j) k[j] = idx[j] < n ? k[j] : 0xFFFFFFFFu;      // m + 2H == p2 reads as the sentinel
         const uint32_t left_max = k[0], right_min = k[1];
-        ok &= (int)(k[2] <= right_min) & (int)(k[3] >= left_max) & (int)(left_max <= k[4]);
-        ok1 &= (int)(k[5] <= right_min) & (int)(k[6] >= left_max);
-        ok2 &= (int)(k[7] <= right_min) & (int)(k[8] >= left_max);
-        ok3 &= (int)(k[9] <= right_min) & (int)(k[10] >= left_max);
+        if (!(k[2] <= right_min && k[3] >= left_max && left_max <= k[4])) bad |= 1u;
+        if (!(k[5] <= right_min && k[6] >= left_max)) bad |= 2u;
+        if (!(k[7] <= right_min && k[8] >= left_max)) bad |= 4u;
+        if (!(k[9] <= right_min && k[10] >= left_max)) bad |= 8u;
     }
-    const int all = __syncthreads_and(ok);
-    const int a1 = __syncthreads_and(ok1), a2 = __syncthreads_and(ok2), a3 = __syncthreads_and(ok3);
+    __shared__ uint32_t s_bad;
+    if (threadIdx.x == 0) s_bad = 0u;
+    __syncthreads();
+    if (bad) atomicOr(&s_bad, bad);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t verdict = all ? s0 : SORT_NO_PLAN;      // the first stage the shifted merge replaces, or none
-        const uint32_t cls = !all ? 0u : a3 ? 3u : a2 ? 2u : a1 ? 1u : 0u;
-        plan[0] = verdict;
-        atomicAdd(&plan[all ? 1 : 2], 1u);             // diagnostics: calls that took the shifted / the per-stage plan
-        plan[3] = 0;                                    // the fallback kernel's barrier counter
-        plan[5] = cls;
-        if (feedback) {
-            feedback[1] = s0; feedback[2] = verdict; feedback[3] = cls; feedback[4] = plan[4];
-            __threadfence_system();
-            feedback[0] = seq;
+        if (s_bad) atomicOr(&plan[8], s_bad);
+        __threadfence();                               // the bits before the ticket
+        if (atomicAdd(&plan[9], 1u) == gridDim.x - 1u) {
+            __threadfence();
+            const uint32_t bits = atomicExch(&plan[8], 0u);              // all workgroups' bits; both words ready for the next call
+            plan[9] = 0u;
+            const bool all = (bits & 1u) == 0u;
+            const uint32_t verdict = all ? s0 : SORT_NO_PLAN;            // the first stage the shifted merge replaces, or none
+            const uint32_t cls = !all ? 0u : !(bits & 8u) ? 3u : !(bits & 4u) ? 2u : !(bits & 2u) ? 1u : 0u;
+            plan[0] = verdict;
+            atomicAdd(&plan[all ? 1 : 2], 1u);         // diagnostics: calls that took the shifted / the per-stage plan
+            plan[3] = 0;                                // the fallback kernel's barrier counter
+            plan[5] = cls;
+            if (feedback) {
+                feedback[1] = s0; feedback[2] = verdict; feedback[3] = cls; feedback[4] = plan[4];
+                __threadfence_system();
+                feedback[0] = seq;
+            }
         }
     }
 }
@@ -800,7 +814,7 @@ static int sort_fuse_stage(uint32_t S, int request) {
 }
 
 uint32_t sort_tile_count(uint32_t n);
-uint32_t sort_plan_word(uint32_t n) { return sort_tile_count(n) - 8u; }
+uint32_t sort_plan_word(uint32_t n) { return sort_tile_count(n) - 16u; }
 
 // One stage >= SORT_LOG_T of the network on `pairs[0 .. n)`: its strided passes, then the tile tails.
 static int launch_stage(hipStream_t st, u64* pairs, uint32_t n, uint32_t p2, uint32_t stage, uint32_t* dirty, int mmax,
@@ -898,7 +912,13 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
         if (s0 && stage == s0) {
             // verdict, then the shifted merge (runs when the verdict is 1); stages s0 .. S-1 below run when it is 0
             const uint32_t H = 1u << (s0 - 1u);
-            hipLaunchKernelGGL(k_late_cert, dim3(1), dim3(256), 0, st, pairs, n, p2, s0, gate,
+            // one boundary per thread, 16-thread workgroups: the key reads' address translations spread over the chip
+            static const uint32_t cert_block = [] { const char* e = getenv("FS_SORT_CERT_BLOCK"); int v = e ? atoi(e) : 16; return (uint32_t)(v < 1 ? 1 : v > 256 ? 256 : v); }();
+            const uint32_t cert_nb = p2 >> s0;
+            uint32_t cert_grid = (cert_nb + cert_block - 1u) / cert_block;
+            if (cert_grid > 256u) cert_grid = 256u;
+            if (cert_grid < 1u) cert_grid = 1u;
+            hipLaunchKernelGGL(k_late_cert, dim3(cert_grid), dim3(cert_block), 0, st, pairs, n, p2, s0, gate,
                                plan ? plan->feedback : (uint32_t*)nullptr, plan ? plan->seq : 0u);
             ++launches;
             if (n > H)
@@ -936,7 +956,7 @@ int launch_bitonic_sort(hipStream_t st, u64* pairs, uint32_t n, uint32_t* dirty,
 uint32_t sort_tile_count(uint32_t n) {
     uint32_t p2 = 1;
     while (p2 < n) p2 <<= 1;
-    return (p2 + SORT_T - 1) / SORT_T + 1u + 8u;   // tiles of the padded array (sentinel tiles included) + the late-stage verdict words
+    return (p2 + SORT_T - 1) / SORT_T + 1u + 16u;  // tiles of the padded array (sentinel tiles included) + the late-stage plan words
 }
 
 }  // namespace fsd
