@@ -473,7 +473,7 @@ fs_status enqueue_step(fs_sim* s, const fs_tick_settings* t) {
     fsd::launch_force(st, P, pos_by_src ? s->pos.p : s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                       s->tex.p, pos_by_src ? s->pos_s.p : s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4,
                       s->aos_live ? (void*)s->aos.p : nullptr, s->side, s->ev_fork, s->ev_join,
-                      s->sortp.general_grid(), s->sortp.general_hint(), 0u, prof ? nullptr : s->sortp.flight_event());
+                      s->sortp.general_grid(), s->sortp.general_hint(), 0u, prof ? nullptr : s->sortp.flight_event(), s->sortp.quad_entries());
     if (pos_by_src) { float2* t = s->pos.p; s->pos.p = s->pos_s.p; s->pos_s.p = t; }   // the spare buffer now holds the state
     if (s->aos_live) s->aos_tick = s->tick;
     if (prof) {
@@ -1488,7 +1488,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
         if (s->adv_lo < s->adv_hi)
             fsd::launch_force(st, PI, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                               s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
-                              s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint());
+                              s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint(), 0u, nullptr, s->sortp.quad_entries());
         if (ev) FS_HIP(hipEventRecord(ev[5], st));      // FS_PASS_FORCE: the interior launch
         // no join here: the next fs_slab_pack leaves the edge columns' slots alone, and fs_slab_step waits for the exchange that
         // follows their chain on the exchange stream; anything else that touches the state joins first (slab_join)
@@ -1497,7 +1497,7 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
     } else {
         fsd::launch_force(st, P, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                           s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
-                          s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint());
+                          s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint(), 0u, nullptr, s->sortp.quad_entries());
         if (ev) { FS_HIP(hipEventRecord(ev[5], st)); FS_HIP(hipEventRecord(ev[6], st)); s->prof_pending += 1; }
     }
     FS_HIP(hipGetLastError());

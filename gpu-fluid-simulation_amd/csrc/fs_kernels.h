@@ -30,7 +30,9 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
                   uint32_t general_grid = 0 /* workgroups of the general kernel; 0: the full grid */,
                   uint32_t* general_hint = nullptr /* host-visible word: entries the general kernel found in its lists */,
                   uint32_t edge_grid = 0 /* != 0: the lean kernel walks only the blocks of the edge columns with this many workgroups */,
-                  hipEvent_t done = nullptr /* completes with the LAST launch of the pass (its own completion signal: no marker packet) */);
+                  hipEvent_t done = nullptr /* completes with the LAST launch of the pass (its own completion signal: no marker packet) */,
+                  uint32_t quad_entries = 0 /* != 0: the pre-registered list is expected to hold about this many blocks, few enough for
+                                               k_force_quad (four lanes per particle) */);
 // pairs != nullptr: the keys are the high words of the sorted pairs (the state of the last step; launch_reorder with
 // key_s == nullptr does not store them a second time), else `key` (an uploaded state).
 void launch_export_aos(hipStream_t st, uint32_t n, const float2* pos, const float2* pred, const float2* vel,

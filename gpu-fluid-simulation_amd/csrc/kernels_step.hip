@@ -705,6 +705,94 @@ __device__ __forceinline__ bool force_sweep_masks(const StepParams& P, const Row
 // branches instead (measured: 0.77 vs 0.86 ms in the bench window, 2.67 vs 2.82 ms in the dense regime).
 struct AosParticle { float2 position, predicted, velocity; float density; uint32_t grid; };   // ParticleInstance, 32 B
 
+// Integration of one particle from its accumulated force sums (compute.wgsl:93-153, :298) and the stores of its new state.
+template <int MODE, bool AOS>
+__device__ __forceinline__ void integrate_store(const StepParams& P, uint32_t i, const float2 me, const float2 mv, const float2 mrec,
+                                                float mrho, const float2 p_own, const ForceAcc& A, uint32_t cx, uint32_t cy,
+                                                const float2* __restrict__ tex, float2* __restrict__ pos_out,
+                                                float2* __restrict__ vel_out, AosParticle* __restrict__ aos_out,
+                                                const float* __restrict__ rho_arr) {
+    const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
+    const float fvy = A.fvy * P.visc_coeff;
+
+    // integrate (compute.wgsl:93-153)
+    float2 v = mv;
+    float2 p = p_own;
+    const float ax = A.fpx + fvx, ay = A.fpy + fvy;
+    if (MODE == 2) {
+        v.x = __builtin_fmaf(ax * mrec.y, P.dt, v.x);
+        v.y = __builtin_fmaf(ay * mrec.y, P.dt, v.y);
+    } else {
+        v.x += __fdiv_rn(ax, mrho) * P.dt;
+        v.y += __fdiv_rn(ay, mrho) * P.dt;
+    }
+    v.x += P.gx * P.dt;
+    v.y += P.gy * P.dt;
+    if (P.mouse_state != 0) {
+        const float dx = P.mouse_x - me.x, dy = P.mouse_y - me.y;
+        const float dist = sqrt_rn(dx * dx + dy * dy);
+        if (dist <= P.mouse_radius) {
+            const float dirx = __fdiv_rn(__fdiv_rn(dx, dist), dist);
+            const float diry = __fdiv_rn(__fdiv_rn(dy, dist), dist);
+            const float ratio = __fdiv_rn(dist, P.mouse_radius);
+            v.x += dirx * P.mouse_power * (float)P.mouse_state * ratio;
+            v.y += diry * P.mouse_power * (float)P.mouse_state * ratio;
+        }
+    }
+    if (!(v.x == v.x && v.y == v.y)) { v.x = 0.0f; v.y = 0.0f; }
+    if (MODE == 2) {
+        const float s2 = __builtin_fmaf(v.x, v.x, v.y * v.y);
+        if (s2 > 250000.0f) { const float k = 500.0f * __builtin_amdgcn_rsqf(s2); v.x *= k; v.y *= k; }
+    } else {
+        // compute.wgsl:118-122.  The square root (an IEEE sequence of ~15 instructions) is only needed near the clamp:
+        // for s2 <= 249 000 it is at most 498.999 < 500 whatever the rounding, so nothing can change; NaN was reset
+        // above and an infinite s2 takes the branch.
+        const float s2 = v.x * v.x + v.y * v.y;
+        if (s2 > 249000.0f) {
+            const float speed = sqrt_rn(s2);
+            if (speed > 500.0f) {
+                v.x = __fdiv_rn(v.x, speed) * 500.0f;
+                v.y = __fdiv_rn(v.y, speed) * 500.0f;
+            }
+        }
+    }
+    p.x += v.x * P.dt;
+    p.y += v.y * P.dt;
+
+    float2 force = make_float2(0.0f, 0.0f);
+    if (!P.tex_zero) {   // uniform; an all-zero field (the default, and the benchmark's) changes nothing below
+        const float uvx = (__fdiv_rn(me.x, P.bounds_x) * 1.0f) + 0.5f;      // compute.wgsl:127
+        const float uvy = (__fdiv_rn(me.y, P.bounds_y) * 1.0f) + 0.5f;
+        const uint32_t px = f32_to_u32_sat(uvx * P.tex_w);
+        const uint32_t py = f32_to_u32_sat(uvy * P.tex_h);
+        const uint32_t tix = py * P.tex_w_u + px;
+        if (tix < P.tex_len) force = tex[tix];
+    }
+    if (force.x != 0.0f || force.y != 0.0f) {                           // compute.wgsl:131-140
+        const float p2wx = __fdiv_rn(P.bounds_x * 2.0f, P.tex_w);
+        const float p2wy = __fdiv_rn(P.bounds_y * 2.0f, P.tex_h);
+        const float fwx = force.x * p2wx, fwy = force.y * p2wy;
+        const float len = sqrt_rn(force.x * force.x + force.y * force.y);
+        const float nx = __fdiv_rn(force.x, len), ny = __fdiv_rn(force.y, len);
+        p.x += fwx;
+        p.y += fwy;
+        const float vn = v.x * nx + v.y * ny;
+        v.x -= (1.0f - P.damping) * vn * nx;
+        v.y -= (1.0f - P.damping) * vn * ny;
+    }
+    if (fabsf(p.x) > P.bs_x) { p.x = P.bs_x * sign_f32(p.x); v.x *= -1.0f * P.damping; }
+    if (fabsf(p.y) > P.bs_y) { p.y = P.bs_y * sign_f32(p.y); v.y *= -1.0f * P.damping; }
+    pos_out[i] = p;
+    vel_out[i] = v;
+    if (AOS) {       // compile-time (even unused, the store costs the plain kernel 5 %): a renderer hand-off is registered (fs_export_handle) — the 32-byte ParticleInstance the
+                     // reference's fragment shader binds (src/simulation.rs:552-559) is written here, no export pass
+        AosParticle a;
+        a.position = p; a.predicted = me; a.velocity = v; a.density = MODE == 2 ? rho_arr[i] : mrho;
+        a.grid = cy * P.grid_u + cx;      // == the sorted key: same expression as cell_of_point(pred) (single-domain handles only)
+        aos_out[i] = a;
+    }
+}
+
 #ifndef FS_FORCE_WAVES
 #define FS_FORCE_WAVES 8
 #endif
@@ -800,85 +888,7 @@ __device__ __forceinline__ void force_block(const StepParams& P, uint32_t blk, u
         return;
     }
     if (!live) return;
-    const float fvx = A.fvx * P.visc_coeff;                             // compute.wgsl:298
-    const float fvy = A.fvy * P.visc_coeff;
-
-    // integrate (compute.wgsl:93-153)
-    float2 v = mv;
-    float2 p = p_own;
-    const float ax = A.fpx + fvx, ay = A.fpy + fvy;
-    if (MODE == 2) {
-        v.x = __builtin_fmaf(ax * mrec.y, P.dt, v.x);
-        v.y = __builtin_fmaf(ay * mrec.y, P.dt, v.y);
-    } else {
-        v.x += __fdiv_rn(ax, mrho) * P.dt;
-        v.y += __fdiv_rn(ay, mrho) * P.dt;
-    }
-    v.x += P.gx * P.dt;
-    v.y += P.gy * P.dt;
-    if (P.mouse_state != 0) {
-        const float dx = P.mouse_x - me.x, dy = P.mouse_y - me.y;
-        const float dist = sqrt_rn(dx * dx + dy * dy);
-        if (dist <= P.mouse_radius) {
-            const float dirx = __fdiv_rn(__fdiv_rn(dx, dist), dist);
-            const float diry = __fdiv_rn(__fdiv_rn(dy, dist), dist);
-            const float ratio = __fdiv_rn(dist, P.mouse_radius);
-            v.x += dirx * P.mouse_power * (float)P.mouse_state * ratio;
-            v.y += diry * P.mouse_power * (float)P.mouse_state * ratio;
-        }
-    }
-    if (!(v.x == v.x && v.y == v.y)) { v.x = 0.0f; v.y = 0.0f; }
-    if (MODE == 2) {
-        const float s2 = __builtin_fmaf(v.x, v.x, v.y * v.y);
-        if (s2 > 250000.0f) { const float k = 500.0f * __builtin_amdgcn_rsqf(s2); v.x *= k; v.y *= k; }
-    } else {
-        // compute.wgsl:118-122.  The square root (an IEEE sequence of ~15 instructions) is only needed near the clamp:
-        // for s2 <= 249 000 it is at most 498.999 < 500 whatever the rounding, so nothing can change; NaN was reset
-        // above and an infinite s2 takes the branch.
-        const float s2 = v.x * v.x + v.y * v.y;
-        if (s2 > 249000.0f) {
-            const float speed = sqrt_rn(s2);
-            if (speed > 500.0f) {
-                v.x = __fdiv_rn(v.x, speed) * 500.0f;
-                v.y = __fdiv_rn(v.y, speed) * 500.0f;
-            }
-        }
-    }
-    p.x += v.x * P.dt;
-    p.y += v.y * P.dt;
-
-    float2 force = make_float2(0.0f, 0.0f);
-    if (!P.tex_zero) {   // uniform; an all-zero field (the default, and the benchmark's) changes nothing below
-        const float uvx = (__fdiv_rn(me.x, P.bounds_x) * 1.0f) + 0.5f;      // compute.wgsl:127
-        const float uvy = (__fdiv_rn(me.y, P.bounds_y) * 1.0f) + 0.5f;
-        const uint32_t px = f32_to_u32_sat(uvx * P.tex_w);
-        const uint32_t py = f32_to_u32_sat(uvy * P.tex_h);
-        const uint32_t tix = py * P.tex_w_u + px;
-        if (tix < P.tex_len) force = tex[tix];
-    }
-    if (force.x != 0.0f || force.y != 0.0f) {                           // compute.wgsl:131-140
-        const float p2wx = __fdiv_rn(P.bounds_x * 2.0f, P.tex_w);
-        const float p2wy = __fdiv_rn(P.bounds_y * 2.0f, P.tex_h);
-        const float fwx = force.x * p2wx, fwy = force.y * p2wy;
-        const float len = sqrt_rn(force.x * force.x + force.y * force.y);
-        const float nx = __fdiv_rn(force.x, len), ny = __fdiv_rn(force.y, len);
-        p.x += fwx;
-        p.y += fwy;
-        const float vn = v.x * nx + v.y * ny;
-        v.x -= (1.0f - P.damping) * vn * nx;
-        v.y -= (1.0f - P.damping) * vn * ny;
-    }
-    if (fabsf(p.x) > P.bs_x) { p.x = P.bs_x * sign_f32(p.x); v.x *= -1.0f * P.damping; }
-    if (fabsf(p.y) > P.bs_y) { p.y = P.bs_y * sign_f32(p.y); v.y *= -1.0f * P.damping; }
-    pos_out[i] = p;
-    vel_out[i] = v;
-    if (AOS) {       // compile-time (even unused, the store costs the plain kernel 5 %): a renderer hand-off is registered (fs_export_handle) — the 32-byte ParticleInstance the
-                     // reference's fragment shader binds (src/simulation.rs:552-559) is written here, no export pass
-        AosParticle a;
-        a.position = p; a.predicted = me; a.velocity = v; a.density = MODE == 2 ? rho_arr[i] : mrho;
-        a.grid = cy * P.grid_u + cx;      // == the sorted key: same expression as cell_of_point(pred) (single-domain handles only)
-        aos_out[i] = a;
-    }
+    integrate_store<MODE, AOS>(P, i, me, mv, mrec, mrho, p_own, A, cx, cy, tex, pos_out, vel_out, aos_out, rho_arr);
 }
 
 // Slab ranks with column-major cell ids (StepParams::transposed): a block's 256 consecutive sorted particles span the cell
@@ -974,6 +984,158 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_GEN
                                          s_red);
             __syncthreads();                         // the LDS stage is reused by the next entry
         }
+    }
+}
+
+// ---- k_force_quad: a SHORT pre-registered list, four lanes per particle (round 4) -------------------------
+// The general kernel's time on a short list — a small scene, a slab rank, the first dense clusters of any scene — is the
+// latency of ONE wave: 64 particles of 60 - 70 in-radius neighbours each, ~11 000 instructions at the single-wave issue rate
+// (40 us per step at 1 M particles, profiles/r04_rejected.md), with most of the chip idle.  Here a deferred wave's 64
+// particles are spread over a whole 256-thread workgroup, FOUR LANES PER PARTICLE: the quad scans the particle's candidates
+// 64 at a time (16 each), ORs the hits into one 64-bit mask in candidate order, and walks it four neighbours per round — lane
+// l evaluates the l-th set bit — after which the four terms are added to the (replicated) sums in lane order by quad
+// broadcasts: neighbour order and association are exactly the reference's.  (A lane without a neighbour contributes +0.0f:
+// the sums start at +0.0f and a round-to-nearest sum is never -0.0f unless both addends are, so x + 0.0f == x bit for bit.)
+// Shared-reciprocal terms only (strict math), native forms (FS_MATH_WGSL_ULP); a pair outside the proven ranges — or a
+// coincident pair, whose direction comes from the particle's serial random sequence — sends the wave to the late list, which
+// k_force_general takes afterwards.  Candidates are read from global memory: no tile, any row length.
+__device__ __forceinline__ uint32_t quad_or(uint32_t x) {
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E /* quad_perm [2, 3, 0, 1] */, 0xf, 0xf, true);
+    return x;
+}
+template <int K> __device__ __forceinline__ float quad_lane(float x) {      // the value lane K of the quad holds
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), K * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void mask64_clear_top(uint32_t& hi, uint32_t& lo) {
+    const uint32_t t = hi ? hi : lo;
+    const uint32_t bit = t ? 0x80000000u >> __builtin_clz(t) : 0u;
+    if (hi) hi ^= bit; else lo ^= bit;
+}
+template <int MODE, bool AOS>
+__global__ __launch_bounds__(FS_BLOCK) void k_force_quad(FS_FORCE_ARGS, uint32_t* __restrict__ hint) {
+    constexpr bool FAST = MODE == 1;
+    const uint32_t n = P.n_live ? *P.n_live : P.n;
+    const uint32_t count = work_count[0];                // written by k_density earlier in the stream
+    if (hint && blockIdx.x == 0 && threadIdx.x == 0) *hint = count + work_count[1];
+    const uint32_t tid = threadIdx.x, l = tid & 3u;
+    const float lim = P.sqr_radius;
+    const uint32_t lbit = 0x80000000u >> l;             // candidate 4 t + l of a chunk: bit 31 - (4 t + l) of its half
+    // consecutive work items to workgroups far apart in dispatch order (grids of 40 k workgroups; see k_force_general)
+    const uint32_t J = gridDim.x >> 3, jq = blockIdx.x >> 3;
+    const uint32_t item0 = ((gridDim.x & 7u) == 0u && J % 5u == 0u) ? ((((jq % 5u) * (J / 5u) + jq / 5u) << 3) | (blockIdx.x & 7u)) : blockIdx.x;
+    for (uint32_t item = item0; item < 4u * count; item += gridDim.x) {
+        const uint32_t blk = worklist[item >> 2], w = item & 3u;
+        if (!((defer_bits[2u * blk] >> w) & 1u)) continue;           // uniform: this wave of the block was not deferred
+        if (!block_may_advance(P, pairs, blk, n)) continue;          // uniform
+        const uint32_t i = blk * FS_BLOCK + w * 64u + (tid >> 2);
+        bool live = i < n;
+        const uint32_t ii = live ? i : n - 1u;
+        const uint32_t lo_fix = quirk_lo_fix(P, pairs, cs, start_ref);
+        const float2 me = pred[ii];
+        const float2 mv = vel_s[ii];
+        const float2 mrec = rho2[ii];
+        const float2 p_own = pos_s[P.pos_by_src ? (uint32_t)pairs[ii] : ii];
+        const float mrho = mrec.x;
+        const float pressure = P.pressure_k * (mrho - P.rest_density);
+        ForceAcc A;
+        A.fpx = A.fpy = A.fvx = A.fvy = 0.0f;
+        A.seed = 0u;                                      // never drawn from here
+        uint32_t cx, cy;
+        int32_t cg;
+        uv_local(P, me, &cx, &cy, &cg);
+        if (P.n_live && !slab_advances(P, cg)) live = false;
+        bool bad = live && !FAST && !(mrec.y > 0.0f);     // the particle's own operands are outside the proven ranges
+        const wave_mask allm = wm(true);
+#pragma unroll 1
+        for (int r = 0; r < 3; ++r) {
+            uint32_t lo = 0, hi = 0;
+            if (live) (void)row_range(P, cs, cx, cy + (uint32_t)(r - 1), lo_fix, &lo, &hi);
+            const uint32_t len = hi > lo ? hi - lo : 0u;
+#pragma unroll 1
+            for (uint32_t c0 = 0; __any(c0 < len); c0 += 64u) {
+                // scan: this lane's sixteen candidates of the chunk, c0 + 4 t + l
+                uint32_t Mh = 0, Ml = 0;
+                {   // all sixteen loads in flight at once: in groups of four every group waited out a full round trip, and the
+                    // round trips, not the arithmetic, were this kernel's time
+                    float2 q[16];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const uint32_t c = c0 + 4u * (uint32_t)t + l;
+                        q[t] = pred[c < len ? lo + c : ii];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const uint32_t c = c0 + 4u * (uint32_t)t + l;
+                        const float ox = q[t].x - me.x, oyv = q[t].y - me.y;
+                        const float r2 = ox * ox + oyv * oyv;
+                        const bool hit = c < len && !(r2 > lim) && !(r == 1 && lo + c == ii);       // compute.wgsl:195,202
+                        const uint32_t b = hit ? lbit >> (4 * (t & 7)) : 0u;
+                        if (t < 8) Mh |= b; else Ml |= b;
+                    }
+                }
+                Mh = quad_or(Mh); Ml = quad_or(Ml);       // the particle's hits in candidate order, in all four lanes
+                const uint32_t jbase = lo + c0;
+                // walk: four neighbours per round, lane l the l-th of them; two register sets, refilled in turn
+#define FS_QSELECT(has, q, v, d)                                                                                     \
+    do {                                                                                                             \
+        uint32_t th = Mh, tl = Ml;                                                                                   \
+        if (l > 0u) mask64_clear_top(th, tl);                                                                        \
+        if (l > 1u) mask64_clear_top(th, tl);                                                                        \
+        if (l > 2u) mask64_clear_top(th, tl);                                                                        \
+        has = (th | tl) != 0u;                                                                                       \
+        const uint32_t kk = th ? (uint32_t)__builtin_clz(th) : 32u + (uint32_t)__builtin_clz(tl | 1u);               \
+        const uint32_t j = has ? jbase + kk : ii;                                                                    \
+        q = pred[j]; v = vel_s[j]; d = rho2[j];                                                                      \
+        mask64_clear_top(Mh, Ml); mask64_clear_top(Mh, Ml); mask64_clear_top(Mh, Ml); mask64_clear_top(Mh, Ml);      \
+    } while (0)
+#define FS_QROUND(has, q, v, d)                                                                                      \
+    do {                                                                                                             \
+        ForceTerms T0;                                                                                               \
+        if (FAST) {                                                                                                  \
+            const float ox = q.x - me.x, oyv = q.y - me.y;                                                           \
+            if (has && ox * ox + oyv * oyv == 0.0f) bad = true;          /* coincident: the serial random direction */ \
+            uint32_t seed = 0u;                                                                                      \
+            T0 = force_terms<true>(P, me, mv, pressure, q, v, d.x, seed);                                            \
+        } else {                                                                                                     \
+            wave_mask good = 0;                                                                                      \
+            T0 = force_terms_shared(P, me, mv, pressure, q, v, d, good);                                             \
+            if ((good | ~wm(has)) != allm) bad = true;                   /* wave-uniform */                          \
+        }                                                                                                            \
+        if (!has) { T0.px = 0.0f; T0.py = 0.0f; T0.vx = 0.0f; T0.vy = 0.0f; }                                        \
+        A.fpx += quad_lane<0>(T0.px); A.fpy += quad_lane<0>(T0.py); A.fvx += quad_lane<0>(T0.vx); A.fvy += quad_lane<0>(T0.vy); \
+        A.fpx += quad_lane<1>(T0.px); A.fpy += quad_lane<1>(T0.py); A.fvx += quad_lane<1>(T0.vx); A.fvy += quad_lane<1>(T0.vy); \
+        A.fpx += quad_lane<2>(T0.px); A.fpy += quad_lane<2>(T0.py); A.fvx += quad_lane<2>(T0.vx); A.fvy += quad_lane<2>(T0.vy); \
+        A.fpx += quad_lane<3>(T0.px); A.fpy += quad_lane<3>(T0.py); A.fvx += quad_lane<3>(T0.vx); A.fvy += quad_lane<3>(T0.vy); \
+    } while (0)
+                bool hA = false, hB = false, hC = false;
+                float2 qA, vA, dA, qB, vB, dB, qC, vC, dC;
+                FS_QSELECT(hA, qA, vA, dA);
+                FS_QSELECT(hB, qB, vB, dB);
+                for (;;) {                                 // two rounds' gathers in flight behind the one being evaluated
+                    if (!__any(hA)) break;
+                    FS_QSELECT(hC, qC, vC, dC);
+                    FS_QROUND(hA, qA, vA, dA);
+                    if (!__any(hB)) break;
+                    FS_QSELECT(hA, qA, vA, dA);
+                    FS_QROUND(hB, qB, vB, dB);
+                    if (!__any(hC)) break;
+                    FS_QSELECT(hB, qB, vB, dB);
+                    FS_QROUND(hC, qC, vC, dC);
+                }
+#undef FS_QROUND
+#undef FS_QSELECT
+            }
+        }
+        if (__syncthreads_or(bad ? 1 : 0)) {             // hand the whole wave to the late list, write nothing
+            if (tid == 0) {
+                const uint32_t old = atomicOr(&defer_bits[2u * blk + 1u], 1u << w);
+                if (old == 0u) worklist[P.n / FS_BLOCK + 8u + atomicAdd(&work_count[1], 1u)] = blk;
+            }
+            continue;
+        }
+        if (live && l == 0u)
+            integrate_store<MODE, AOS>(P, i, me, mv, mrec, mrho, p_own, A, cx, cy, tex, pos_out, vel_out, aos_out, rho_arr);
     }
 }
 
@@ -1160,7 +1322,7 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
                   const float2* rho2, const uint32_t* cs, const uint32_t* start_ref, const u64* pairs, const float2* tex,
                   float2* pos_out, float2* vel_out, const float* rho_arr, uint32_t* defer_bits, uint32_t* worklist,
                   uint32_t* work_count, void* aos_out, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
-                  uint32_t general_grid, uint32_t* general_hint, uint32_t edge_grid, hipEvent_t done) {
+                  uint32_t general_grid, uint32_t* general_hint, uint32_t edge_grid, hipEvent_t done, uint32_t quad_entries) {
     const uint32_t nb = nblk(P.n), grid = xcd_grid(nb, P.xcd_chunk_log2);
     hipEvent_t stop_ev = nullptr;      // set for the pass's last launch only
 #define FS_LAUNCH_FORCE(K, M, A, G, S, ...)                                                                         \
@@ -1189,6 +1351,14 @@ void launch_force(hipStream_t st, const StepParams& P, const float2* pos_s, cons
         (void)hipStreamWaitEvent(st, ev_join, 0);
         stop_ev = done;
         FS_LAUNCH_FORCE_MODE(k_force_general, (nb < 256u ? nb : 256u), st, 1u, (uint32_t*)nullptr);
+    } else if (quad_entries != 0u && P.fast_math != 2 && (P.fast_math == 1 || P.share_div)) {
+        // a short pre-registered list (the host's view of it, a few steps old): four lanes per particle (k_force_quad), then the
+        // late list — what the lean kernel and the quad kernel gave up on — in the general kernel
+        uint32_t qg = 8u * quad_entries;                 // 4 work items per entry, twice that for a list that has grown since
+        qg = qg < 80u ? 80u : qg > 4080u ? 4080u : (qg + 39u) / 40u * 40u;       // a multiple of 40 (the kernel's item mapping)
+        FS_LAUNCH_FORCE_MODE(k_force_quad, qg, st, general_hint);
+        stop_ev = done;
+        FS_LAUNCH_FORCE_MODE(k_force_general, 240u, st, 1u, (uint32_t*)nullptr);
     } else {
         stop_ev = done;
         FS_LAUNCH_FORCE_MODE(k_force_general, gg, st, 2u, general_hint);      // both lists in one follow-up launch

@@ -45,6 +45,9 @@ struct SortPolicy {
         if (fx) fixed_stage = atoi(fx);
         force_single = tr && atoi(tr) != 0;
         { const char* inj = getenv("FS_SORT_INJECT_TIMEOUT"); inject_timeout = inj && atoi(inj) != 0; }
+        { const char* q = getenv("FS_FORCE_QUAD_MAX"); if (q) quad_max = (uint32_t)atoi(q); }
+        { const char* q = getenv("FS_FORCE_QUAD_MIN"); if (q) quad_min = (uint32_t)atoi(q); }
+        { const char* q = getenv("FS_FORCE_QUAD_ALWAYS"); quad_always = q && atoi(q) != 0; }
         enabled = !(e && atoi(e) == 0) && !fx;
         // the words are allocated even when the plan policy is off: fb[6] is the force pass's work report (general_grid())
         hipError_t r = hipHostMalloc((void**)&fb, 8 * sizeof(uint32_t), hipHostMallocMapped);
@@ -109,6 +112,17 @@ struct SortPolicy {
         return entries == 0 ? 240u : entries < 128u ? 1040u : 4080u;      // multiples of 40: k_force_general's entry mapping
     }
     uint32_t* general_hint() const { return fb ? fb + 6 : nullptr; }
+    // ... and whether that list is short enough for k_force_quad (the latency case: a small scene, a slab rank, the first dense
+    // clusters); 0: no.  Below quad_min blocks the extra launch costs more than the quad kernel saves (one unfit block: 13 + 4 us
+    // against 16).  Performance only: every choice gives the same bits.
+    uint32_t quad_max = 512, quad_min = 8;   // FS_FORCE_QUAD_MAX / _MIN (blocks; max 0 disables), read when the handle is created
+    bool quad_always = false;                // FS_FORCE_QUAD_ALWAYS=1 (tests): k_force_quad in every step, whatever the list held
+    uint32_t quad_entries() const {
+        if (!fb) return 0;
+        const uint32_t entries = ((const volatile uint32_t*)fb)[6];
+        if (quad_always) return entries > 64u ? entries : 64u;
+        return entries >= quad_min && entries <= quad_max ? entries : 0u;
+    }
 
     // After a synchronisation of the simulation's stream: did the stand-by kernel (k_late_fallback) report a grid-barrier
     // time-out in any of the steps enqueued so far?  From that step on the particle order is undefined (include/fluidsim.h), so

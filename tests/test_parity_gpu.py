@@ -429,6 +429,47 @@ def test_dense_cluster_exercises_overflow_paths(fs, orc, sort_mode):
     assert cnt.max() > 150          # the scene really has hot cells
 
 
+def _dense_scene(fs, n=8192, seed=17):
+    st = fs.SimulationSettings(n, 0.1, 0.2, (40.0, 30.0))
+    tick = fs.default_tick_settings(gravity=(0.0, 9.81))
+    rng = np.random.default_rng(seed)
+    p = fs.reference_lattice(st, (0.0, 0.0))
+    idx = rng.choice(n, 3000, replace=False)
+    p["position"][idx] = rng.uniform(-0.3, 0.3, size=(3000, 2)).astype(np.float32) + np.float32([5.0, -4.0])
+    p["position"][idx[:64]] = p["position"][idx[64:128]]          # coincident pairs: the serial random direction (compute.wgsl:211)
+    p["predicted_position"] = p["position"]
+    p["velocity"] = rng.uniform(-0.5, 0.5, size=(n, 2)).astype(np.float32)
+    return st, tick, p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", ["ieee", "ulp"])
+def test_force_quad_kernel_changes_no_bit(fs, orc, monkeypatch, math):
+    """k_force_quad (a short list of deferred waves: four lanes per particle, the four terms of a round added in lane order by quad
+    broadcasts) must leave every bit where the lane-per-particle general kernel leaves it — dense clusters, rows of hundreds of
+    candidates, coincident pairs (which it hands to the general kernel), both math modes that use it; strict math also against
+    the oracle.  FS_FORCE_QUAD_ALWAYS=1 puts it into every step (otherwise the host picks it from the list length a few steps ago)."""
+    st, tick, p = _dense_scene(fs)
+    mm = fs.FS_MATH_IEEE if math == "ieee" else fs.FS_MATH_WGSL_ULP
+    monkeypatch.setenv("FS_FORCE_QUAD_ALWAYS", "1")
+    quad = fs.FluidSimulation(st, device=0, math_mode=mm)
+    monkeypatch.delenv("FS_FORCE_QUAD_ALWAYS"); monkeypatch.setenv("FS_FORCE_QUAD_MAX", "0")
+    plain = fs.FluidSimulation(st, device=0, math_mode=mm)
+    monkeypatch.delenv("FS_FORCE_QUAD_MAX")
+    ref = orc.OracleSim(st) if math == "ieee" else None
+    quad.upload_particles(p); plain.upload_particles(p)
+    if ref: ref.set_particles(p)
+    for s in range(6):
+        quad.tick(tick); plain.tick(tick)
+        a, b = quad.download_particles(), plain.download_particles()
+        assert a.tobytes() == b.tobytes(), f"{math} step {s}: the quad kernel changed the state"
+        if ref:
+            ref.step(tick)
+            assert_particles_equal(a, ref.particles(), f"quad/{math} step {s}")
+    quad.close(); plain.close()
+    if ref: ref.close()
+
+
 def test_wgsl_ulp_math_mode_within_tolerance(fs, orc):
     """FS_MATH_WGSL_ULP (native rcp/sqrt in the force pass) is not bit-exact; it must stay within the
     stated tolerance of the IEEE oracle: one step from identical state — keys and density exact (density
