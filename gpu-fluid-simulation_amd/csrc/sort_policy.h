@@ -113,15 +113,17 @@ struct SortPolicy {
     }
     uint32_t* general_hint() const { return fb ? fb + 6 : nullptr; }
     // ... and whether that list is short enough for k_force_quad (the latency case: a small scene, a slab rank, the first dense
-    // clusters); 0: no.  Below quad_min blocks the extra launch costs more than the quad kernel saves (one unfit block: 13 + 4 us
-    // against 16).  Performance only: every choice gives the same bits.
-    uint32_t quad_max = 512, quad_min = 8;   // FS_FORCE_QUAD_MAX / _MIN (blocks; max 0 disables), read when the handle is created
-    bool quad_always = false;                // FS_FORCE_QUAD_ALWAYS=1 (tests): k_force_quad in every step, whatever the list held
+    // clusters); 0: no.  fb[7] = the deferred waves that have a row of more than 32 candidates: without such waves (blocks that
+    // merely missed the LDS tile: a slab rank's sparse ghost columns, a particle of spray) the quad kernel's chain of global round
+    // trips plus the extra launch is SLOWER than the general kernel (one rank of 8: 0.218 -> 0.229 ms).  Performance only: every
+    // choice gives the same bits.
+    uint32_t quad_max = 512, quad_min = 16;  // FS_FORCE_QUAD_MAX (blocks in the lists; 0 disables) / _MIN (heavy waves), read when the handle is created
+    bool quad_always = false;                // FS_FORCE_QUAD_ALWAYS=1 (tests): k_force_quad in every step, whatever the lists held
     uint32_t quad_entries() const {
         if (!fb) return 0;
-        const uint32_t entries = ((const volatile uint32_t*)fb)[6];
+        const uint32_t entries = ((const volatile uint32_t*)fb)[6], heavy = ((const volatile uint32_t*)fb)[7];
         if (quad_always) return entries > 64u ? entries : 64u;
-        return entries >= quad_min && entries <= quad_max ? entries : 0u;
+        return heavy >= quad_min && entries <= quad_max ? entries : 0u;
     }
 
     // After a synchronisation of the simulation's stream: did the stand-by kernel (k_late_fallback) report a grid-barrier
