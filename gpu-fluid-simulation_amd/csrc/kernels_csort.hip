@@ -175,7 +175,7 @@ __global__ __launch_bounds__(CS_BLOCK) void k_cs_fixreorder(StepParams P, uint32
     if (threadIdx.x == 0) {                      // the force pass's worklists of this step (same block size and count)
         force_defer[2u * blockIdx.x] = 0u;
         force_defer[2u * blockIdx.x + 1u] = 0u;
-        if (blockIdx.x == 0) { force_work_count[0] = 0u; force_work_count[1] = 0u; force_work_count[2] = 0u; }
+        if (blockIdx.x == 0) { force_work_count[0] = 0u; force_work_count[1] = 0u; }
     }
     if (p >= n) return;
     if (SLAB) {

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_slab_reorder(StepParams P, uint32_
     if (threadIdx.x == 0) {                      // the force pass's worklists of this step (same block size)
         force_defer[2u * blockIdx.x] = 0u;
         force_defer[2u * blockIdx.x + 1u] = 0u;
-        if (blockIdx.x == 0) { force_work_count[0] = 0u; force_work_count[1] = 0u; force_work_count[2] = 0u; }
+        if (blockIdx.x == 0) { force_work_count[0] = 0u; force_work_count[1] = 0u; }
     }
     if (i >= cap) return;
     const u64 pr = pairs[i];

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_reorder(StepParams P, const u64* _
     if (threadIdx.x == 0) {                      // the force pass's worklists of this step (same block size and count)
         force_defer[2u * blockIdx.x] = 0u;       // [2 blk] pre-registered by k_density, [2 blk + 1] found late by k_force
         force_defer[2u * blockIdx.x + 1u] = 0u;
-        if (blockIdx.x == 0) { force_work_count[0] = 0u; force_work_count[1] = 0u; force_work_count[2] = 0u; }
+        if (blockIdx.x == 0) { force_work_count[0] = 0u; force_work_count[1] = 0u; }
     }
     if (i >= P.n) return;
     const u64 pr = pairs[i];
@@ -195,9 +195,6 @@ __device__ __forceinline__ void density_block(const StepParams& P, uint32_t blk,
         if ((unfit || __any(long_row)) && __builtin_amdgcn_ballot_w64(live) != 0 && (threadIdx.x & 63u) == 0u) {
             const uint32_t old = atomicOr(&force_defer[2u * blk], 1u << (threadIdx.x >> 6));
             if (old == 0u) force_work[atomicAdd(&force_count[0], 1u)] = blk;
-            // [2]: the HEAVY waves among the deferred ones (a row of more than 32 candidates: dense clusters) — what the host picks
-            // the follow-up kernel by (k_force_quad pays for those, not for the light waves of a block that merely missed the tile)
-            if (__any(long_row)) atomicAdd(&force_count[2], 1u);
         }
     }
     float rho = 0.0f;
@@ -965,7 +962,7 @@ __global__ __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(FS_GEN
     const uint32_t n = P.n_live ? *P.n_live : P.n;
     // how much work the lists held: the host sizes the next steps' grid of this kernel from it (a few steps late,
     // through pinned memory; an idle launch costs what its workgroups cost to come and go)
-    if (hint && blockIdx.x == 0 && threadIdx.x == 0) { hint[0] = which == 2u ? work_count[0] + work_count[1] : work_count[which]; hint[1] = work_count[2]; }
+    if (hint && blockIdx.x == 0 && threadIdx.x == 0) *hint = which == 2u ? work_count[0] + work_count[1] : work_count[which];
     // Which entry a workgroup starts with.  A list shorter than the grid (a small scene, the first dense clusters) would
     // otherwise be worked off by the FIRST workgroups of the grid, neighbours in dispatch order, while most of the chip runs the
     // workgroups that find nothing: grids of 40 k workgroups (sort_policy.h) deal consecutive entries to the 8 XCDs and, inside
@@ -1020,7 +1017,7 @@ __global__ __launch_bounds__(FS_BLOCK) void k_force_quad(FS_FORCE_ARGS, uint32_t
     constexpr bool FAST = MODE == 1;
     const uint32_t n = P.n_live ? *P.n_live : P.n;
     const uint32_t count = work_count[0];                // written by k_density earlier in the stream
-    if (hint && blockIdx.x == 0 && threadIdx.x == 0) { hint[0] = count + work_count[1]; hint[1] = work_count[2]; }
+    if (hint && blockIdx.x == 0 && threadIdx.x == 0) *hint = count + work_count[1];
     const uint32_t tid = threadIdx.x, l = tid & 3u;
     const float lim = P.sqr_radius;
     const uint32_t lbit = 0x80000000u >> l;             // candidate 4 t + l of a chunk: bit 31 - (4 t + l) of its half

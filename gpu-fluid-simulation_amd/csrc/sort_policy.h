@@ -113,17 +113,19 @@ struct SortPolicy {
     }
     uint32_t* general_hint() const { return fb ? fb + 6 : nullptr; }
     // ... and whether that list is short enough for k_force_quad (the latency case: a small scene, a slab rank, the first dense
-    // clusters); 0: no.  fb[7] = the deferred waves that have a row of more than 32 candidates: without such waves (blocks that
-    // merely missed the LDS tile: a slab rank's sparse ghost columns, a particle of spray) the quad kernel's chain of global round
-    // trips plus the extra launch is SLOWER than the general kernel (one rank of 8: 0.218 -> 0.229 ms).  Performance only: every
-    // choice gives the same bits.
-    uint32_t quad_max = 512, quad_min = 16;  // FS_FORCE_QUAD_MAX (blocks in the lists; 0 disables) / _MIN (heavy waves), read when the handle is created
-    bool quad_always = false;                // FS_FORCE_QUAD_ALWAYS=1 (tests): k_force_quad in every step, whatever the lists held
+    // clusters); 0: no.  Lists of fewer than quad_min blocks are, as a rule, blocks that merely missed the LDS tile (a slab rank's
+    // sparse ghost columns, a particle of spray: light waves): for those the quad kernel's chain of global round trips plus the
+    // extra launch is SLOWER than the general kernel (one unfit block 13 + 4 us against 16; one rank of 8 0.218 -> 0.229 ms with
+    // a bound of 8).  Telling heavy waves from light ones on the device was tried and cost more than it gave: one more
+    // same-address atomic per registered wave cost k_density 5 % in the dense regime, a per-wave counter in k_force_general
+    // cost that kernel its last free register (scratch, +4 %).  Performance only: every choice gives the same bits.
+    uint32_t quad_max = 512, quad_min = 64;  // FS_FORCE_QUAD_MAX / _MIN (blocks; max 0 disables), read when the handle is created
+    bool quad_always = false;                // FS_FORCE_QUAD_ALWAYS=1 (tests): k_force_quad in every step, whatever the list held
     uint32_t quad_entries() const {
         if (!fb) return 0;
-        const uint32_t entries = ((const volatile uint32_t*)fb)[6], heavy = ((const volatile uint32_t*)fb)[7];
+        const uint32_t entries = ((const volatile uint32_t*)fb)[6];
         if (quad_always) return entries > 64u ? entries : 64u;
-        return heavy >= quad_min && entries <= quad_max ? entries : 0u;
+        return entries >= quad_min && entries <= quad_max ? entries : 0u;
     }
 
     // After a synchronisation of the simulation's stream: did the stand-by kernel (k_late_fallback) report a grid-barrier
