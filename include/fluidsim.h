@@ -305,16 +305,23 @@ fs_status fs_slab_upload_owned(fs_sim* sim, const fs_particle* src, size_t n);
  * fs_slab_column_histogram still describe the stored state in the window it was built with. */
 fs_status fs_slab_set_window(fs_sim* sim, uint32_t own_lo, uint32_t own_hi);
 size_t fs_slab_message_bytes(const fs_sim* sim);
-/* Begin a step: predict, classify, fill the two outgoing device messages (NULL = no neighbour).
- * OVERLAPPED step (the default with the counting sort; fs_slab_overlapped() == 1): ghosts never enter the rank's sorted
- * array, so the call goes on to enqueue everything that does not need the incoming messages — sort and reorder of the
- * carried-over particles, density, and the force pass of the INTERIOR columns (farther than the boundary zone from a
- * neighboured edge) — behind the pack, and the exchange runs beside that on a second stream.  fs_slab_step then finishes
- * the boundary columns on a small second array ("strip": ghost + boundary + 2 context columns and the received records). */
+/* Begin a step: predict, classify, fill the two outgoing device messages (NULL = no neighbour).  Three step modes
+ * (fs_slab_overlapped(): 1 edge-first — the default with the counting sort —, 2 strips, 0 serial; fs_slab_config.sort_mode
+ * flags, FS_SLAB_MODE in the environment), one call pattern: fs_slab_pack -> exchange -> fs_slab_step.
+ *   EDGE-FIRST (1): fs_slab_step forks after its reorder pass — the handle's exchange stream (fs_slab_comm_stream) advances
+ *     the owned columns within the boundary zone of a neighboured edge first and builds the NEXT tick's two messages from
+ *     their new state right away, into the buffers the last fs_slab_pack was given; the interior columns' density / force
+ *     launches run beside that on the simulation's stream.  The next fs_slab_pack finds the messages built (same buffers,
+ *     same delta, same window: otherwise it builds them itself) and only classifies the interior columns' slots for the sort.
+ *     Keep the send buffers of a step untouched until the next fs_slab_pack returns, and exchange on the exchange stream
+ *     (fs_slab_exchange does; other transports: fs_slab_comm_begin / _end).
+ *   STRIPS (2): ghosts never enter the rank's sorted array; fs_slab_pack also enqueues sort, reorder, density and the interior
+ *     columns' force launch; fs_slab_step finishes the boundary columns on a small second array after the exchange.
+ *   SERIAL (0): pack, exchange and the whole step one after the other on the simulation's stream. */
 fs_status fs_slab_pack(fs_sim* sim, const fs_tick_settings* tick, void* send_left, void* send_right);
 /* Finish the step with the two incoming device messages (NULL = no neighbour). */
 fs_status fs_slab_step(fs_sim* sim, const void* recv_left, const void* recv_right);
-/* Overlapped step: 1 / 0; owned columns per neighboured edge left to the strips (default 4, at least 3; set it to
+/* Step mode (see fs_slab_pack); owned columns per neighboured edge in the boundary zone (default 4, at least 3; set it to
  * 3 + the columns the fastest particle can cross in one step — a migrant that lands closer than 3 columns to the interior
  * is counted in fs_slab_counters.far_halo; a window edge moved by fs_slab_set_window widens the next step's zone by itself). */
 int fs_slab_overlapped(const fs_sim* sim);
