@@ -16,7 +16,9 @@ namespace fsd {
 #define CS_BLOCK 256
 #define CS_ITEMS 16
 #define CS_TILE (CS_BLOCK * CS_ITEMS)
-#define CS_RANK_MAX 2048u    // longest cell segment k_cs_fixreorder still orders by source index (see there)
+#ifndef CS_RANK_MAX
+#define CS_RANK_MAX 8192u    // longest cell segment k_cs_fixreorder still orders by source index (see there)
+#endif
 
 // ---- pipeline (round 3): 4 launches, no memset, atomics only in the histogram -------------------------------
 //   k_cs_hist        predict + key per particle; per-cell histogram with wave-aggregated atomics.  The value the
@@ -192,8 +194,11 @@ __global__ __launch_bounds__(CS_BLOCK) void k_cs_fixreorder(StepParams P, uint32
     } else {
         // A cell with more than CS_RANK_MAX particles (a degenerate or uploaded state: thousands of coincident particles, keys
         // clamped into one cell): the serial rank loop is O(m^2) per cell — 1e5 particles in one cell would be a multi-second
-        // kernel.  Such a cell keeps its ARRIVAL order (p = start + ticket, what k_cs_scatter produced): still
-        // a correct cell sort, no longer independent of the atomics' order inside that one cell.
+        // kernel; at the bound a step of a scene made of nothing but such cells costs ~40 ms.  A larger cell keeps its
+        // ARRIVAL order (p = start + ticket, what k_cs_scatter produced): still a correct cell sort, but the order inside
+        // that one cell — and with it the order of its particles' sums — then depends on the atomics' order: not the oracle's
+        // stable order, not repeatable from run to run (tools/fuzz_parity.py skips such states in this sort mode; the
+        // reference's own bitonic order, FS_SORT_BITONIC, has no such bound).
         rank = p - lo;
     }
     const uint32_t d = lo + rank;

@@ -320,10 +320,36 @@ def test_shuffled_upload_on_a_large_grid_takes_the_wide_tile_path(fs, orc):
     sim.close()
 
 
+def test_counting_sort_orders_a_cell_of_5000_particles_like_the_stable_sort(fs, orc):
+    """Up to CS_RANK_MAX = 8192 particles per cell the counting sort's order inside a cell is the source order — the oracle's
+    std::stable_sort — whatever order the histogram atomics were served in: 5000 particles in one cell (tools/fuzz_parity.py
+    case 15 found the earlier bound of 2048 with a compressive scene), bit-exact over two steps."""
+    n = 16384
+    st = fs.SimulationSettings(n, 0.1, 0.2, (40.0, 30.0))
+    tick = fs.default_tick_settings(gravity=(0.0, 9.81))
+    sim = fs.FluidSimulation(st, device=0, sort_mode=fs.FS_SORT_COUNTING)
+    ref = orc.OracleSim(st)
+    rng = np.random.default_rng(23)
+    p = ref.particles()
+    idx = rng.choice(n, 5000, replace=False)
+    p["position"][idx] = rng.uniform(0.01, 0.19, size=(5000, 2)).astype(np.float32) + np.float32([4.0, -3.0])   # inside one cell
+    p["predicted_position"] = p["position"]
+    p["velocity"] = rng.uniform(-0.05, 0.05, size=(n, 2)).astype(np.float32)
+    ref.set_particles(p); sim.upload_particles(p)
+    for s in range(2):
+        sim.tick(tick)
+        ref.step(tick, stable_sort=True)
+        want = ref.particles()
+        if s == 0:
+            assert np.unique(want["grid"], return_counts=True)[1].max() >= 4000
+        assert_particles_equal(sim.download_particles(), want, f"big cell step {s}")
+    sim.close(); ref.close()
+
+
 def test_counting_sort_survives_a_cell_with_30k_particles(fs):
     """k_cs_fixreorder ranks a slot inside its cell segment with a serial loop — O(m^2) for a cell of m particles, on top
     of the m^2 pairs the force pass must visit anyway (which is why this test stops at 30 000 coincident particles, ~1e9 pairs).
-    Segments above 2048 now keep their arrival order.  The step must finish with a valid arrangement (keys sorted, nothing lost,
+    Segments above 8192 particles keep their arrival order.  The step must finish with a valid arrangement (keys sorted, nothing lost,
     finite predicted positions)."""
     import time
     n = 1 << 18
