@@ -1460,10 +1460,15 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
         // small fixed grids (fs_device.h EdgeBlocks)
         const uint32_t eg = s->transposed ? FS_EDGE_GRID : 0u;
         hipStream_t es = s->comm;
-        if (!forked) {
-            FS_HIP(hipEventRecord(s->ev_fork2, st));
-            FS_HIP(hipStreamWaitEvent(es, s->ev_fork2, 0));
-        }
+        if (!forked) FS_HIP(hipEventRecord(s->ev_fork2, st));
+        // the simulation's stream first (its force launch is the long one: the host must not leave that stream empty while it
+        // enqueues the six launches of the edge chain — seen under the profiler, where a launch costs 10 us), then the chain
+        if (s->adv_lo < s->adv_hi)
+            fsd::launch_force(st, PI, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
+                              s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
+                              s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint(), 0u, nullptr, s->sortp.quad_entries());
+        if (ev) FS_HIP(hipEventRecord(ev[5], st));      // FS_PASS_FORCE: the interior launch
+        if (!forked) FS_HIP(hipStreamWaitEvent(es, s->ev_fork2, 0));
         fsd::launch_force(es, PE, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
                           s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, nullptr,
                           nullptr, nullptr, 256u, nullptr, eg);
@@ -1485,11 +1490,6 @@ fs_status fs_slab_step(fs_sim* s, const void* recv_left, const void* recv_right)
             s->prepacked = true;
             s->pp_delta = s->last_tick.delta; s->pp_lo = s->slab_cfg.own_lo; s->pp_hi = s->slab_cfg.own_hi;
         }
-        if (s->adv_lo < s->adv_hi)
-            fsd::launch_force(st, PI, s->pos_s.p, s->vel_s.p, s->pred.p, s->rho2.p, s->cs.p, s->start_ref.p, s->pairs.p,
-                              s->tex.p, s->pos.p, s->vel.p, s->rho.p, s->fdefer.p, s->fwork.p, s->counter.p + 4, nullptr, s->side,
-                              s->ev_fork, s->ev_join, s->sortp.general_grid(), s->sortp.general_hint(), 0u, nullptr, s->sortp.quad_entries());
-        if (ev) FS_HIP(hipEventRecord(ev[5], st));      // FS_PASS_FORCE: the interior launch
         // no join here: the next fs_slab_pack leaves the edge columns' slots alone, and fs_slab_step waits for the exchange that
         // follows their chain on the exchange stream; anything else that touches the state joins first (slab_join)
         s->join_pending = true;

@@ -24,16 +24,26 @@ with open(path) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")))
 rows.sort()
 byq = collections.defaultdict(list)
+allm = []
 for k, (s, e, n, q) in enumerate(rows):
     if delim in n:
         byq[q].append(k)
-# the queue with the most delimiter launches, ties -> the one whose launches come second in time (the middle rank of tools/slab_overhead.py)
-qs = sorted(byq, key=lambda q: (-len(byq[q]), rows[byq[q][0]][0]))
-q = qs[int(sys.argv[4])] if len(sys.argv) > 4 else qs[min(1, len(qs) - 1)]
-marks = byq[q]
-a, b = marks[which], marks[which + 1] if which + 1 < 0 or which + 1 < len(marks) else len(rows)
+        allm.append((k, q))
+if len(sys.argv) > 4:
+    # the queue with the most delimiter launches, ties -> the one whose launches come second in time (the middle rank of tools/slab_overhead.py)
+    qs = sorted(byq, key=lambda q: (-len(byq[q]), rows[byq[q][0]][0]))
+    q = qs[int(sys.argv[4])]
+    marks = byq[q]
+    a = marks[which]
+else:
+    # `which` counts delimiter launches over ALL queues in time order (negative: from the end of the run, where only the measured
+    # handle is still stepping); the step shown runs to the next delimiter launch on the same queue
+    a, q = allm[which]
+    marks = byq[q]
+nxt = [m for m in marks if m > a]
+b = nxt[0] if nxt else len(rows)
 t0 = rows[a][0]
-tend = rows[b][0]
+tend = rows[b][0] if b < len(rows) else rows[-1][1]
 print(f"step of queue {q}: {delim} launch #{which} .. the next one; offsets in us from its start")
 for s, e, n, qq in rows[a:]:
     if s >= tend:
