@@ -5,6 +5,7 @@
 // pred.w carries the density for the force pass), so a neighbour is two 16-B loads.
 // A row of the 27-cell sweep (fixed z,y; x-1..x+1) is ONE contiguous index range, visited
 // z outer, y, x inner, index ascending = the oracle's order, so sums are bit-identical.
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -1052,11 +1053,15 @@ static fs_status enqueue3(fs_sim3* s, const fs3_tick_settings* t) {
     else hipLaunchKernelGGL(k3_density<0>, gridf, blockf, 0, st, P, s->pred.p, s->cs.p, s->vel_s.p, s->masks.p, s->key.p);
     if (ev) H3(hipEventRecord(ev[4], st));
     // positions ping-pong: read the previous state (s->pos, source order) through the pairs, write the new one into s->pos_s
-    if (tol) hipLaunchKernelGGL(k3_force<2>, gridf, blockf, 0, st, P, s->pos.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos_s.p, s->vel.p, fm, s->key.p, s->pairs.p);
-    else hipLaunchKernelGGL(k3_force<0>, gridf, blockf, 0, st, P, s->pos.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos_s.p, s->vel.p, fm, s->key.p, s->pairs.p);
+    // the step's completion event (sort_policy.h: the host stays at most four steps ahead) rides on the force kernel as its
+    // completion signal — no marker packet behind it (engine.hip fs_step does the same); a profiled step records markers anyway
+    hipEvent_t done = ev ? nullptr : s->sortp.flight_event();
+    if (tol) hipExtLaunchKernelGGL(k3_force<2>, gridf, blockf, 0, st, nullptr, done, 0, P, s->pos.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos_s.p, s->vel.p, fm, s->key.p, s->pairs.p);
+    else hipExtLaunchKernelGGL(k3_force<0>, gridf, blockf, 0, st, nullptr, done, 0, P, s->pos.p, s->vel_s.p, s->pred.p, s->cs.p, s->pos_s.p, s->vel.p, fm, s->key.p, s->pairs.p);
     { float4* t = s->pos.p; s->pos.p = s->pos_s.p; s->pos_s.p = t; }
     if (ev) { H3(hipEventRecord(ev[5], st)); H3(hipEventRecord(ev[6], st)); /* FS_PASS_BOUNDARY: slab handles only */ s->pending += 1; }
-    H3(s->sortp.step_enqueued(st));
+    if (ev) H3(s->sortp.step_enqueued(st));
+    else s->sortp.step_bound();
     H3(hipGetLastError());
     return FS_OK;
 }
