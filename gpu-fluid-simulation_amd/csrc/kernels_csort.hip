@@ -17,7 +17,7 @@ namespace fsd {
 #define CS_ITEMS 16
 #define CS_TILE (CS_BLOCK * CS_ITEMS)
 #ifndef CS_RANK_MAX
-#define CS_RANK_MAX 8192u    // longest cell segment k_cs_fixreorder still orders by source index (see there)
+#define CS_RANK_MAX 2048u    // longest cell segment k_cs_fixreorder ranks with its serial loop; longer ones are sorted (cs_sort_segment)
 #endif
 
 // ---- pipeline (round 3): 4 launches, no memset, atomics only in the histogram -------------------------------
@@ -159,12 +159,50 @@ __global__ __launch_bounds__(CS_BLOCK) void k_cs_scatter(uint32_t n, uint32_t nc
         if ((uint32_t)(e[it] >> 32) != FS_DEAD_KEY) slot_src[start[it] + (uint32_t)e[it]] = i0 + (uint32_t)it * CS_BLOCK;
 }
 
+// ---- cells too large for the serial rank loop (round 4) ----------------------------------------------------------------
+// k_cs_fixreorder ranks a slot inside its cell segment of slot_src with a serial loop: O(m^2) for a cell of m particles — fine
+// for the tens a cell holds, a multi-second kernel for 1e5 coincident particles.  A segment longer than CS_RANK_MAX
+// is therefore SORTED in place, by the workgroup that holds the cell's first slot (at most one such cell starts in a
+// workgroup: the next cell start is more than CS_RANK_MAX slots away): the reference's own ascending flip / disperse network
+// on the 28-bit source indices (distinct values; positions past the segment act as +inf, which an ascending-only network
+// never moves), all 256 threads, global memory, a barrier per pass — O(m log^2 m), ~1 ms for 1e5.  It then sets bit 31 of
+// the segment's first entry (source indices are < 2^28); every thread of that cell — in this workgroup or in a later one —
+// waits for the bit and takes slot p's particle as it now stands there: rank = p - lo, the stable order.  The wait cannot
+// deadlock: the sorting workgroup has the lowest index of all that hold slots of the cell, so it was dispatched no later,
+// and its own duty precedes any wait of its threads.  (Bounded all the same, like the sort's stand-by barrier.)
+#define CS_SORTED_FLAG 0x80000000u
+#define CS_SRC_MASK 0x0FFFFFFFu
+__device__ __forceinline__ void cs_cmpx(uint32_t* v, uint32_t m, uint32_t a, uint32_t b) {      // a < b
+    if (b < m) {
+        const uint32_t x = v[a], y = v[b];
+        if (x > y) { v[a] = y; v[b] = x; }
+    }
+}
+__device__ __forceinline__ void cs_sort_segment(uint32_t* v, uint32_t m) {      // all threads of the workgroup
+    uint32_t p2 = 1;
+    while (p2 < m) p2 <<= 1;
+    for (uint32_t h = 1; h < p2; h <<= 1) {
+        for (uint32_t t = threadIdx.x; t < (p2 >> 1); t += CS_BLOCK) {           // flip: i <-> mirror inside blocks of 2h
+            const uint32_t q = (t / h) * 2u * h, r = t % h;
+            cs_cmpx(v, m, q + r, q + 2u * h - 1u - r);
+        }
+        __syncthreads();
+        for (uint32_t hh = h >> 1; hh >= 1u; hh >>= 1) {                          // disperse: distance hh
+            for (uint32_t t = threadIdx.x; t < (p2 >> 1); t += CS_BLOCK) {
+                const uint32_t q = (t / hh) * 2u * hh, r = t % hh;
+                cs_cmpx(v, m, q + r, q + r + hh);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Fused rank fix-up + reorder pass (k_reorder<false> / k_slab_reorder<false> of round 2).  SLAB: `n` = slot capacity,
 // the live count is cs[ncell]; slots past it become DEAD pairs.
 template <bool SLAB>
 __global__ __launch_bounds__(CS_BLOCK) void k_cs_fixreorder(StepParams P, uint32_t n, const u64* __restrict__ kt,
                                                             const uint32_t* __restrict__ cs,
-                                                            const uint32_t* __restrict__ slot_src, u64* __restrict__ pairs,
+                                                            uint32_t* slot_src, u64* __restrict__ pairs,
                                                             const float2* __restrict__ pos_in, const float2* __restrict__ vel_in,
                                                             float2* __restrict__ pos_s, float2* __restrict__ vel_s,
                                                             float2* __restrict__ pred_s, uint32_t* __restrict__ key_s,
@@ -174,33 +212,50 @@ __global__ __launch_bounds__(CS_BLOCK) void k_cs_fixreorder(StepParams P, uint32
                                                             const uint32_t* __restrict__ n_dev) {
     const uint32_t p = blockIdx.x * CS_BLOCK + threadIdx.x;
     if (n_dev) { const uint32_t m = *n_dev; n = m < n ? m : n; }     // device-side slot count (see k_cs_scatter)
+    __shared__ uint32_t s_seg[2];
     if (threadIdx.x == 0) {                      // the force pass's worklists of this step (same block size and count)
         force_defer[2u * blockIdx.x] = 0u;
         force_defer[2u * blockIdx.x + 1u] = 0u;
         if (blockIdx.x == 0) { force_work_count[0] = 0u; force_work_count[1] = 0u; }
+        s_seg[1] = 0u;
     }
-    if (p >= n) return;
-    if (SLAB) {
+    bool act = p < n;
+    if (SLAB && act) {
         const uint32_t n_live = cs[P.ncell];
-        if (p >= n_live) { pairs[p] = ((u64)FS_DEAD_KEY << 32) | (u64)p; owned[p] = 0; return; }
+        if (p >= n_live) { pairs[p] = ((u64)FS_DEAD_KEY << 32) | (u64)p; owned[p] = 0; act = false; }
     }
-    const uint32_t src = slot_src[p];
-    const uint32_t key = (uint32_t)(kt[src] >> 32);
-    const uint32_t k = key < P.ncell ? key : P.ncell - 1u;
-    const uint32_t lo = cs[k], hi = cs[k + 1u];
+    uint32_t src = 0, key = FS_DEAD_KEY, lo = 0, hi = 0;
+    if (act) {
+        // (while another workgroup sorts the segment, an entry is always SOME member of it: enough to find the cell)
+        src = __hip_atomic_load(&slot_src[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & CS_SRC_MASK;
+        key = (uint32_t)(kt[src] >> 32);
+        const uint32_t k = key < P.ncell ? key : P.ncell - 1u;
+        lo = cs[k]; hi = cs[k + 1u];
+    }
+    const bool big = act && hi - lo > CS_RANK_MAX;
+    __syncthreads();                             // s_seg cleared
+    if (big && p == lo) { s_seg[0] = lo; s_seg[1] = hi; }
+    __syncthreads();
+    if (s_seg[1] != 0u) {                        // block-uniform: this workgroup holds the first slot of a large cell
+        cs_sort_segment(slot_src + s_seg[0], s_seg[1] - s_seg[0]);
+        if (threadIdx.x == 0) {
+            __threadfence();
+            atomicOr(&slot_src[s_seg[0]], CS_SORTED_FLAG);
+        }
+    }
     uint32_t rank = 0;
-    if (hi - lo <= CS_RANK_MAX) {
-        for (uint32_t q = lo; q < hi; ++q) rank += slot_src[q] < src ? 1u : 0u;
-    } else {
-        // A cell with more than CS_RANK_MAX particles (a degenerate or uploaded state: thousands of coincident particles, keys
-        // clamped into one cell): the serial rank loop is O(m^2) per cell — 1e5 particles in one cell would be a multi-second
-        // kernel; at the bound a step of a scene made of nothing but such cells costs ~40 ms.  A larger cell keeps its
-        // ARRIVAL order (p = start + ticket, what k_cs_scatter produced): still a correct cell sort, but the order inside
-        // that one cell — and with it the order of its particles' sums — then depends on the atomics' order: not the oracle's
-        // stable order, not repeatable from run to run (tools/fuzz_parity.py skips such states in this sort mode; the
-        // reference's own bitonic order, FS_SORT_BITONIC, has no such bound).
+    if (big) {
+        uint32_t spins = 0;
+        while (!(__hip_atomic_load(&slot_src[lo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & CS_SORTED_FLAG)) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 26)) break;     // (cannot happen: see above; the cell would keep a valid but unordered arrangement)
+        }
+        src = __hip_atomic_load(&slot_src[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & CS_SRC_MASK;
         rank = p - lo;
+    } else if (act) {
+        for (uint32_t q = lo; q < hi; ++q) rank += (slot_src[q] & CS_SRC_MASK) < src ? 1u : 0u;
     }
+    if (!act) return;
     const uint32_t d = lo + rank;
     pairs[d] = ((u64)key << 32) | (u64)src;
     const float2 ps = pos_in[src];

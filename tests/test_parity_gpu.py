@@ -321,9 +321,10 @@ def test_shuffled_upload_on_a_large_grid_takes_the_wide_tile_path(fs, orc):
 
 
 def test_counting_sort_orders_a_cell_of_5000_particles_like_the_stable_sort(fs, orc):
-    """Up to CS_RANK_MAX = 8192 particles per cell the counting sort's order inside a cell is the source order — the oracle's
-    std::stable_sort — whatever order the histogram atomics were served in: 5000 particles in one cell (tools/fuzz_parity.py
-    case 15 found the earlier bound of 2048 with a compressive scene), bit-exact over two steps."""
+    """The counting sort's order inside a cell is the source order — the oracle's std::stable_sort — whatever order the histogram
+    atomics were served in, for a cell of ANY size: up to CS_RANK_MAX = 2048 particles by the serial rank loop, beyond by sorting
+    the cell's segment in place (kernels_csort.hip cs_sort_segment).  5000 particles in one cell (tools/fuzz_parity.py case 15
+    found that such cells were left in arrival order), bit-exact over two steps."""
     n = 16384
     st = fs.SimulationSettings(n, 0.1, 0.2, (40.0, 30.0))
     tick = fs.default_tick_settings(gravity=(0.0, 9.81))
@@ -349,7 +350,7 @@ def test_counting_sort_orders_a_cell_of_5000_particles_like_the_stable_sort(fs, 
 def test_counting_sort_survives_a_cell_with_30k_particles(fs):
     """k_cs_fixreorder ranks a slot inside its cell segment with a serial loop — O(m^2) for a cell of m particles, on top
     of the m^2 pairs the force pass must visit anyway (which is why this test stops at 30 000 coincident particles, ~1e9 pairs).
-    Segments above 8192 particles keep their arrival order.  The step must finish with a valid arrangement (keys sorted, nothing lost,
+    Segments above CS_RANK_MAX are sorted in place by one workgroup (O(m log^2 m)).  The step must finish with a valid arrangement (keys sorted, nothing lost,
     finite predicted positions)."""
     import time
     n = 1 << 18
