@@ -663,7 +663,11 @@ def test_rebalance_inputs_equal_the_host_path_world2(fs, tmp_path):
     stay unverified on hardware."""
     script = tmp_path / "reb_worker.py"
     script.write_text(REBALANCE_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    import socket
+    with socket.socket() as sk:          # a port nobody holds right now (a fixed one can sit in TIME_WAIT from an earlier run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), cwd=ROOT, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
